@@ -1,0 +1,158 @@
+/*
+ * urgym.h — C-ABI of the MI355X-native vectorised UR5e reach environment (liburgym_hip.so).
+ *
+ * The reference (WanqingXia/UR-gym) is pure Python on top of pybullet and has no FFI seam of its own
+ * (SURVEY.md §8b).  The drop-in boundary is the Gymnasium Env surface of RobotTaskEnv, vectorised over N
+ * environments; this header is what a ctypes binding of that surface calls.  Each entry point names the
+ * reference interface it replaces (file:line under /root/reference).
+ *
+ * Conventions
+ *   - plain C, no torch types: the caller (PyTorch-ROCm tensors in ur_gym_amd/vector_env.py) allocates and
+ *     owns EVERY buffer; the library borrows the raw device pointers registered with urgym_bind() and keeps
+ *     only its constant tables (hull vertices, chain constants) uploaded at urgym_create().
+ *   - state is float64 like the reference's internal state, struct-of-arrays [field][N] so that one lane per
+ *     environment reads/writes coalesced; observations are float32 row-major [N][dim] exactly as
+ *     RobotTaskEnv._get_obs casts them (UR_gym/envs/core.py:252-261).
+ *   - all launches are asynchronous on the caller-supplied HIP stream (hipStream_t passed as void*).
+ *   - return value: 0 = ok, <0 = error (urgym_last_error() gives the text).  No C++ exception crosses the ABI.
+ *   - one handle per (process, device); calls on one handle are not re-entrant.
+ */
+#ifndef URGYM_H
+#define URGYM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define URGYM_ABI_VERSION 1
+
+/* env kinds = the reference's registered ids (UR_gym/__init__.py:19-42, UR_gym/envs/ur_tasks.py:37-90) */
+enum {
+  URGYM_ENV_ORI = 0, /* UR5OriReach-v1 : ReachOri, reach.py:141-236 */
+  URGYM_ENV_OBS = 1, /* UR5ObsReach-v1 : ReachObs, reach.py:239-374 */
+  URGYM_ENV_DYN = 2, /* UR5DynReach-v1 : ReachDyn, reach.py:576-785 */
+};
+
+/* error codes */
+enum {
+  URGYM_OK = 0,
+  URGYM_ERR_ARG = -1,
+  URGYM_ERR_HIP = -2,
+  URGYM_ERR_STATE = -3,
+};
+
+/* bits of the per-env status word (device-side anomalies; SURVEY.md §5 "failure detection") */
+enum {
+  URGYM_STATUS_NAN = 1,              /* a NaN reached the reward/obs (utils.py:65-67 prints in the reference) */
+  URGYM_STATUS_RESET_EXHAUSTED = 2,  /* rejection sampling hit max_reset_tries (reach.py:668-675 loops forever) */
+  URGYM_STATUS_RESET_COLLISION = 4,  /* "Collision after reset, this should not happen" (reach.py:682-683) */
+  URGYM_STATUS_PENETRATION = 8,      /* a core-shape overlap was clamped (no EPA depth; DESIGN.md "deviations") */
+  URGYM_STATUS_GJK_ITER = 16,        /* GJK hit its iteration cap */
+};
+
+/* One POD config struct: every constant the reference hard-codes in its task constructors. */
+typedef struct urgym_config {
+  int32_t env_kind;          /* URGYM_ENV_* */
+  int32_t num_envs;          /* N */
+  int32_t max_episode_steps; /* TimeLimit, UR_gym/__init__.py:41 -> 100 */
+  int32_t auto_reset;        /* 1: finished envs are reset inside urgym_step (gymnasium VectorEnv semantics) */
+  int32_t check_collision;   /* 1: reference behaviour; 0: BASELINE.json configs[1] "FK + reward only" */
+  int32_t max_reset_tries;   /* bound on the reference's unbounded rejection loop */
+  int32_t dyn_motion_steps;  /* reach.py:735 -> 25 */
+  int32_t reserved0;
+  double action_scale;       /* UR5.py:276,314: pi*0.1 is applied as two float32 products; kept for reporting */
+  double dt;                 /* pyb_setup.py:40,47-50: 20 substeps / 500 Hz = 0.04 s */
+  double distance_threshold; /* reach.py:148/246/590 -> 0.05 */
+  double ori_threshold;      /* reach.py:149/591 -> 0.0873 */
+  double w_collision;        /* -500 */
+  double w_success;          /* +200 */
+  double w_distance;         /* Ori/Dyn -70, Obs -100 */
+  double w_orientation;      /* Ori/Dyn -30, Obs 0 */
+  double w_link[5];          /* Dyn: [8,2.4,1.2,1.2,0.2]/13*50 (reach.py:596-597); Obs: 100 each (reach.py:255,371) */
+  double near_threshold;     /* 0.2 (reach.py:371,783) */
+  double collision_margin;   /* 0.01 (pyb_setup.py:402,411,422) */
+  double target_clearance;   /* 0.1 (reach.py:322,675) */
+  double min_travel;         /* Dyn: 1.0 (reach.py:675) */
+  double dyn_time_duration;  /* Dyn: 2.0 (reach.py:736) */
+  double goal_low[3], goal_high[3]; /* reach.py:151-152 / 248-249 / 584-585 */
+  double obst_low[3], obst_high[3]; /* reach.py:250-251 / 586-587 */
+  double neutral_q[6];       /* UR5.py:262 */
+} urgym_config;
+
+/* Device pointers, all owned by the caller.  SoA state: X[f][n] at X[f*N + n]. */
+typedef struct urgym_buffers {
+  /* ---- per-env state (float64) ---- */
+  double* q;          /* [6][N] joint angles (pybullet joint state, UR5.py:346-351) */
+  double* goal;       /* [6][N] goal xyz + rpy (Obs uses rows 0..2) */
+  double* obst_start; /* [6][N] obstacle start xyz+rpy  (Obs: the static obstacle; reach.py:263,582) */
+  double* obst_end;   /* [6][N] obstacle end xyz+rpy    (Dyn only) */
+  double* obst_pos;   /* [3][N] current obstacle position (Bullet base position) */
+  double* obst_quat;  /* [4][N] current obstacle orientation xyzw */
+  double* obst_vel;   /* [6][N] per-episode (v, omega) applied while step_count < dyn_motion_steps */
+  double* link_dist;  /* [5][N] task.link_dist == task.last_dist (reach.py:680-681,780-782) */
+  int32_t* step_count;/* [N] ReachDyn.step_num == TimeLimit._elapsed_steps */
+  int32_t* episode_id;/* [N] number of resets so far (RNG counter) */
+  /* ---- outputs ---- */
+  float* observation;   /* [N][obs_dim]  */
+  float* achieved_goal; /* [N][goal_dim] */
+  float* desired_goal;  /* [N][goal_dim] */
+  float* reward;        /* [N] */
+  uint8_t* terminated;  /* [N] */
+  uint8_t* truncated;   /* [N] */
+  uint8_t* is_success;  /* [N] info["is_success"] (core.py:272,315) */
+  uint8_t* collision;   /* [N] task.collision */
+  /* terminal observation of envs that were auto-reset in this step (valid where terminated|truncated) */
+  float* final_observation;   /* [N][obs_dim]  */
+  float* final_achieved_goal; /* [N][goal_dim] */
+  float* final_desired_goal;  /* [N][goal_dim] */
+  int32_t* status;      /* [N] URGYM_STATUS_* bits, sticky until cleared by the caller */
+  /* ---- scratch ---- */
+  int32_t* done_list;   /* [N] compacted ids of envs to reset */
+  int32_t* done_count;  /* [2] ping-pong counters */
+} urgym_buffers;
+
+/* ABI version of the loaded library (== URGYM_ABI_VERSION). */
+int urgym_abi_version(void);
+
+/* Fill cfg with the reference's constants for env_kind (reach.py constructors). */
+int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg);
+
+/* Observation layout: obs_dim = 18|26|35, goal_dim = 6|3|6 (core.py:241-247; reach.py:189,307,653). */
+int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
+
+/* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device`. */
+int urgym_create(const urgym_config* cfg, int device, void** handle);
+int urgym_destroy(void* handle);
+
+/* Register the caller-owned device buffers (all pointers must stay valid until the next bind/destroy). */
+int urgym_bind(void* handle, const urgym_buffers* bufs);
+
+/* Replaces RobotTaskEnv.reset (core.py:263-273) for every env whose mask byte is non-zero (NULL = all).
+ * `seed` re-keys the counter-based RNG; pass UINT64_MAX to keep the current key. */
+int urgym_reset(void* handle, const uint8_t* mask_dev, uint64_t seed, void* stream);
+
+/* Replaces RobotTaskEnv.step (core.py:303-317) + TimeLimit (UR_gym/__init__.py:41) for all N envs.
+ * actions_dev: float32 [N][6] row-major, clipped to [-1,1] inside (UR5.py:274-275). */
+int urgym_step(void* handle, const float* actions_dev, void* stream);
+
+/* K consecutive urgym_step calls enqueued back to back: actions_dev is [K][N][6]. */
+int urgym_rollout(void* handle, const float* actions_dev, int num_steps, void* stream);
+
+/* Replaces Reach*.set_goal / set_goal_and_obstacle (reach.py:202-204, 328-335, 702-713): the caller has
+ * overwritten goal / obst_start / obst_end (and possibly q) for the masked envs; this recomputes obstacle pose,
+ * velocity, collision, link_dist and the observation for them, leaving step_count untouched. */
+int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream);
+
+/* Average device time (microseconds) of the step kernel over the calls since the last query, measured with
+ * hipEvents on the launch stream; returns <0 if timing was not enabled. */
+int urgym_enable_timing(void* handle, int enable);
+int urgym_query_timing(void* handle, double* step_kernel_us, double* reset_kernel_us, int* launches);
+
+const char* urgym_last_error(void* handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* URGYM_H */

@@ -1,0 +1,350 @@
+// urgym_device.h — device-side math for the fused UR5e reach kernels (gfx950 only).
+//
+// Numeric plan: everything that the reference evaluates in float64 and that feeds an
+// output with a large weight (FK chain, Euler/quaternion conversions, pose distances, the GJK simplex) is done in
+// float64 here as well; only the O(#vertices) support scan over a convex hull runs in float32 on LDS-resident
+// vertices (it only has to pick the right vertex — the vertex is then re-read and transformed in float64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace urgym {
+
+struct D3 {
+  double x, y, z;
+};
+__device__ __forceinline__ D3 d3(double x, double y, double z) { return D3{x, y, z}; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 operator-(D3 a) { return d3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return d3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ D3 cross(D3 a, D3 b) {
+  return d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ double len2(D3 a) { return dot(a, a); }
+__device__ __forceinline__ D3 sel(bool c, D3 a, D3 b) { return d3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
+
+// row-major 3x3 + translation; every index is a compile-time constant so the whole thing lives in VGPRs
+struct X3 {
+  double r[9];
+  D3 t;
+};
+__device__ __forceinline__ D3 rot(const X3& T, D3 v) {
+  return d3(fma(T.r[0], v.x, fma(T.r[1], v.y, T.r[2] * v.z)), fma(T.r[3], v.x, fma(T.r[4], v.y, T.r[5] * v.z)),
+            fma(T.r[6], v.x, fma(T.r[7], v.y, T.r[8] * v.z)));
+}
+__device__ __forceinline__ D3 rotT(const X3& T, D3 v) {
+  return d3(fma(T.r[0], v.x, fma(T.r[3], v.y, T.r[6] * v.z)), fma(T.r[1], v.x, fma(T.r[4], v.y, T.r[7] * v.z)),
+            fma(T.r[2], v.x, fma(T.r[5], v.y, T.r[8] * v.z)));
+}
+__device__ __forceinline__ D3 apply(const X3& T, D3 v) { return rot(T, v) + T.t; }
+// C = A^-1 * B for rigid transforms
+__device__ __forceinline__ X3 rel(const X3& A, const X3& B) {
+  X3 C;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) C.r[i * 3 + j] = fma(A.r[i], B.r[j], fma(A.r[3 + i], B.r[3 + j], A.r[6 + i] * B.r[6 + j]));
+  C.t = rotT(A, B.t - A.t);
+  return C;
+}
+
+struct Q4 {
+  double x, y, z, w;
+};
+__device__ __forceinline__ Q4 qmul(Q4 a, Q4 b) {
+  return Q4{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+            a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+__device__ __forceinline__ void quat_to_rot(Q4 q, double r[9]) {
+  double d = q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w;
+  double s = 2.0 / d;
+  double xs = q.x * s, ys = q.y * s, zs = q.z * s;
+  double wx = q.w * xs, wy = q.w * ys, wz = q.w * zs, xx = q.x * xs, xy = q.x * ys, xz = q.x * zs;
+  double yy = q.y * ys, yz = q.y * zs, zz = q.z * zs;
+  r[0] = 1.0 - (yy + zz); r[1] = xy - wz; r[2] = xz + wy;
+  r[3] = xy + wz; r[4] = 1.0 - (xx + zz); r[5] = yz - wx;
+  r[6] = xz - wy; r[7] = yz + wx; r[8] = 1.0 - (xx + yy);
+}
+// rotation matrix -> quaternion, largest-diagonal branch selection (what Bullet's getLinkState hands to
+// getEulerFromQuaternion; pyb_setup.py:244-248)
+__device__ __forceinline__ Q4 rot_to_quat(const double r[9]) {
+  double tr = r[0] + r[4] + r[8];
+  Q4 q;
+  if (tr > 0.0) {
+    double s = sqrt(tr + 1.0);
+    q.w = 0.5 * s;
+    s = 0.5 / s;
+    q.x = (r[7] - r[5]) * s; q.y = (r[2] - r[6]) * s; q.z = (r[3] - r[1]) * s;
+  } else if (r[0] >= r[4] && r[0] >= r[8]) {  // i = 0
+    double s = sqrt(r[0] - r[4] - r[8] + 1.0);
+    q.x = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (r[7] - r[5]) * s; q.y = (r[3] + r[1]) * s; q.z = (r[6] + r[2]) * s;
+  } else if (r[4] >= r[8]) {  // i = 1
+    double s = sqrt(r[4] - r[8] - r[0] + 1.0);
+    q.y = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (r[2] - r[6]) * s; q.z = (r[7] + r[5]) * s; q.x = (r[1] + r[3]) * s;
+  } else {  // i = 2
+    double s = sqrt(r[8] - r[0] - r[4] + 1.0);
+    q.z = 0.5 * s;
+    s = 0.5 / s;
+    q.w = (r[3] - r[1]) * s; q.x = (r[2] + r[6]) * s; q.y = (r[5] + r[7]) * s;
+  }
+  return q;
+}
+// pybullet getQuaternionFromEuler (pyb_setup.py:151-152): q = qz(yaw) qy(pitch) qx(roll)
+__device__ __forceinline__ Q4 quat_from_rpy(double roll, double pitch, double yaw) {
+  double sr, cr, sp, cp, sy, cy;
+  sincos(0.5 * roll, &sr, &cr);
+  sincos(0.5 * pitch, &sp, &cp);
+  sincos(0.5 * yaw, &sy, &cy);
+  return Q4{sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy, cr * cp * cy + sr * sp * sy};
+}
+// pybullet getEulerFromQuaternion (pyb_setup.py:190,248) incl. the |sin pitch| >= 0.99999 branches
+__device__ __forceinline__ void rpy_from_quat(Q4 q, double& roll, double& pitch, double& yaw) {
+  const double HALF_PI = 1.5707963267948966;
+  double sarg = -2.0 * (q.x * q.z - q.w * q.y);
+  if (sarg <= -0.99999) {
+    roll = 0.0; pitch = -HALF_PI; yaw = 2.0 * atan2(q.x, -q.y);
+  } else if (sarg >= 0.99999) {
+    roll = 0.0; pitch = HALF_PI; yaw = 2.0 * atan2(-q.x, q.y);
+  } else {
+    double sqx = q.x * q.x, sqy = q.y * q.y, sqz = q.z * q.z, squ = q.w * q.w;
+    roll = atan2(2.0 * (q.y * q.z + q.w * q.x), squ - sqx - sqy + sqz);
+    pitch = asin(sarg);
+    yaw = atan2(2.0 * (q.x * q.y + q.w * q.z), squ + sqx - sqy - sqz);
+  }
+}
+// scipy Rotation.from_euler('ZYX',[a0,a1,a2]) as utils.angular_distance uses it (utils.py:47-55): qz(a0) qy(a1) qx(a2)
+__device__ __forceinline__ Q4 quat_ZYX(double a0, double a1, double a2) {
+  double s0, c0, s1, c1, s2, c2;
+  sincos(0.5 * a0, &s0, &c0);
+  sincos(0.5 * a1, &s1, &c1);
+  sincos(0.5 * a2, &s2, &c2);
+  Q4 zy{-s0 * s1, c0 * s1, s0 * c1, c0 * c1};  // qz * qy
+  return qmul(zy, Q4{s2, 0.0, 0.0, c2});
+}
+__device__ __forceinline__ double angular_distance(const double a[3], const double b[3]) {
+  Q4 qa = quat_ZYX(a[0], a[1], a[2]), qb = quat_ZYX(b[0], b[1], b[2]);
+  double d = qa.x * qb.x + qa.y * qb.y + qa.z * qb.z + qa.w * qb.w;
+  d = fmin(1.0, fmax(-1.0, d));
+  return 2.0 * acos(fabs(d));
+}
+
+// ---------------------------------------------------------------------------------------------- Philox4x32-10
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+
+// ---------------------------------------------------------------------------------------------- shapes / GJK
+enum { SH_HULL = 0, SH_CYLZ = 1, SH_BOX = 2, SH_POINT = 3 };
+struct ShapeDesc {
+  int type;
+  int blk_off;  // hull: first 4-vertex block in the LDS table
+  int nblk;     // hull: number of 4-vertex blocks
+  double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
+  D3 center;    // a point inside (initial direction only)
+};
+
+// LDS hull table layout: block b (4 vertices) = { x0..x3, y0..y3, z0..z3 } -> three 16-byte reads per block.
+// Scan = two-level arg-max: per block max of 4 dots, compared once against the running best; the winning block
+// is re-read afterwards to recover the vertex.  4.25 VALU ops per vertex instead of 6.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f* lds_f4_ptr;  // explicit LDS pointer: ds_read_b128, never flat
+
+__device__ __forceinline__ D3 hull_support(lds_f4_ptr tab, int blk_off, int nblk, float dx, float dy, float dz) {
+  lds_f4_ptr t4 = tab + blk_off * 3;
+  float best = -3.0e38f;
+  int bb = 0;
+  for (int b = 0; b < nblk; b++) {
+    v4f X = t4[b * 3 + 0], Y = t4[b * 3 + 1], Z = t4[b * 3 + 2];
+    float t0 = fmaf(Z.x, dz, fmaf(Y.x, dy, X.x * dx));
+    float t1 = fmaf(Z.y, dz, fmaf(Y.y, dy, X.y * dx));
+    float t2 = fmaf(Z.z, dz, fmaf(Y.z, dy, X.z * dx));
+    float t3 = fmaf(Z.w, dz, fmaf(Y.w, dy, X.w * dx));
+    float m = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+    bool g = m > best;
+    best = g ? m : best;
+    bb = g ? b : bb;
+  }
+  v4f X = t4[bb * 3 + 0], Y = t4[bb * 3 + 1], Z = t4[bb * 3 + 2];
+  float t0 = fmaf(Z.x, dz, fmaf(Y.x, dy, X.x * dx));
+  float t1 = fmaf(Z.y, dz, fmaf(Y.y, dy, X.y * dx));
+  float t2 = fmaf(Z.z, dz, fmaf(Y.z, dy, X.z * dx));
+  D3 r = d3(X.w, Y.w, Z.w);
+  if (t2 >= best) r = d3(X.z, Y.z, Z.z);
+  if (t1 >= best) r = d3(X.y, Y.y, Z.y);
+  if (t0 >= best) r = d3(X.x, Y.x, Z.x);
+  return r;
+}
+
+__device__ __forceinline__ D3 support_local(lds_f4_ptr tab, const ShapeDesc& s, D3 d) {
+  if (s.type == SH_HULL) {
+    return hull_support(tab, s.blk_off, s.nblk, (float)d.x, (float)d.y, (float)d.z);
+  } else if (s.type == SH_CYLZ) {
+    double sn = sqrt(d.x * d.x + d.y * d.y);
+    double hz = d.z < 0.0 ? -s.hz : s.hz;
+    if (sn != 0.0) {
+      double k = s.hx / sn;
+      return d3(d.x * k, d.y * k, hz);
+    }
+    return d3(s.hx, 0.0, hz);
+  } else if (s.type == SH_BOX) {
+    return d3(d.x >= 0.0 ? s.hx : -s.hx, d.y >= 0.0 ? s.hy : -s.hy, d.z >= 0.0 ? s.hz : -s.hz);
+  }
+  return d3(0.0, 0.0, 0.0);
+}
+
+// closest point of triangle (a,b,c) to the origin (Voronoi-region tests, Ericson RTCD §5.1.5); mask bit i = vertex i used
+__device__ __forceinline__ D3 tri_closest(D3 a, D3 b, D3 c, int& mask) {
+  D3 ab = b - a, ac = c - a;
+  double d1 = -dot(ab, a), d2 = -dot(ac, a);
+  if (d1 <= 0.0 && d2 <= 0.0) { mask = 1; return a; }
+  double d3_ = -dot(ab, b), d4 = -dot(ac, b);
+  if (d3_ >= 0.0 && d4 <= d3_) { mask = 2; return b; }
+  double vc = d1 * d4 - d3_ * d2;
+  if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) { mask = 3; return a + ab * (d1 / (d1 - d3_)); }
+  double d5 = -dot(ab, c), d6 = -dot(ac, c);
+  if (d6 >= 0.0 && d5 <= d6) { mask = 4; return c; }
+  double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { mask = 5; return a + ac * (d2 / (d2 - d6)); }
+  double va = d3_ * d6 - d5 * d4;
+  if (va <= 0.0 && (d4 - d3_) >= 0.0 && (d5 - d6) >= 0.0) {
+    mask = 6;
+    return b + (c - b) * ((d4 - d3_) / ((d4 - d3_) + (d5 - d6)));
+  }
+  double den = 1.0 / (va + vb + vc);
+  mask = 7;
+  return a + ab * (vb * den) + ac * (vc * den);
+}
+
+enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4 };
+
+// Distance between the CORE shapes A (posed by T = pose of A in B's frame) and B (canonical frame).
+// stop_above: as soon as a separating direction proves core distance > stop_above the search stops and the lower
+// bound is returned with GJK_SEPARATED (boolean "closer than margin?" queries); pass a huge value for exact distance.
+__device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const ShapeDesc& A, const X3& T, const ShapeDesc& B,
+                                                 double stop_above, int& info) {
+  const double TOL = 1.0e-10;     // relative gap on the squared distance (Bullet double build: 1e-12)
+  const double TINY2 = 1.0e-20;   // |v|^2 below this = cores touching/overlapping
+  info = 0;
+  D3 v = apply(T, A.center) - B.center;
+  if (len2(v) < 1.0e-12) v = d3(0.0, 1.0, 0.0);
+  double sq = len2(v);
+  D3 s0 = d3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+  int n = 0;
+  for (int it = 0; it < 64; it++) {
+    D3 p = apply(T, support_local(tab, A, rotT(T, -v)));
+    D3 q = support_local(tab, B, v);
+    D3 w = p - q;
+    double delta = dot(v, w);
+    if (delta > 0.0 && delta * delta > sq * stop_above * stop_above) {
+      info |= GJK_SEPARATED;
+      return delta / sqrt(sq);
+    }
+    if (n > 0) {
+      // new support point already in the simplex, or no measurable gap left: v is the closest point
+      bool dup = (len2(w - s0) <= 1e-24) || (n > 1 && len2(w - s1) <= 1e-24) || (n > 2 && len2(w - s2) <= 1e-24);
+      if (dup || (sq - delta) <= sq * TOL) return sqrt(sq);
+    }
+    // add w
+    if (n == 0) s0 = w; else if (n == 1) s1 = w; else if (n == 2) s2 = w; else s3 = w;
+    n++;
+    D3 nv;
+    int mask;
+    if (n == 1) {
+      nv = s0;
+      mask = 1;
+    } else if (n == 2) {
+      D3 e = s1 - s0;
+      double t = -dot(e, s0);
+      double ee = dot(e, e);
+      if (t <= 0.0) { nv = s0; mask = 1; }
+      else if (t >= ee) { nv = s1; mask = 2; }
+      else { nv = s0 + e * (t / ee); mask = 3; }
+    } else if (n == 3) {
+      nv = tri_closest(s0, s1, s2, mask);
+    } else {
+      // tetrahedron: test the four faces; face f = (a,b,c) with opposite vertex o
+      double best = 1.0e300;
+      nv = d3(0, 0, 0);
+      mask = 15;
+      bool any_out = false, degen = false;
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        D3 a = (f == 3) ? s1 : s0;
+        D3 b = (f == 0) ? s1 : ((f == 1) ? s2 : s3);
+        D3 c = (f == 0) ? s2 : ((f == 1) ? s3 : ((f == 2) ? s1 : s2));
+        D3 o = (f == 0) ? s3 : ((f == 1) ? s1 : ((f == 2) ? s2 : s0));
+        D3 nrm = cross(b - a, c - a);
+        double signp = -dot(a, nrm), signd = dot(o - a, nrm);
+        if (signd * signd < 1.0e-16) degen = true;
+        if (signp * signd < 0.0) {
+          any_out = true;
+          int m3;
+          D3 pt = tri_closest(a, b, c, m3);
+          double l = len2(pt);
+          if (l < best) {
+            best = l;
+            nv = pt;
+            // map (a,b,c) bits back to (s0,s1,s2,s3)
+            int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
+            mask = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+          }
+        }
+      }
+      if (degen) return sqrt(sq);  // sliver tetrahedron: keep the last good closest point (Bullet: degenerate simplex 3)
+      if (!any_out) {
+        info |= GJK_PENETRATING;
+        return 0.0;
+      }
+    }
+    // keep only the vertices that support the closest point, in order
+    {
+      D3 t0 = s0, t1 = s1, t2 = s2, t3 = s3;
+      int k = 0;
+      D3 o0 = t0, o1 = t1, o2 = t2;
+      // first used
+      int i0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : ((mask & 4) ? 2 : 3));
+      int rest = mask & ~(1 << i0);
+      int i1 = (rest & 1) ? 0 : ((rest & 2) ? 1 : ((rest & 4) ? 2 : 3));
+      int rest2 = rest & ~(1 << i1);
+      int i2 = (rest2 & 1) ? 0 : ((rest2 & 2) ? 1 : ((rest2 & 4) ? 2 : 3));
+      o0 = (i0 == 0) ? t0 : ((i0 == 1) ? t1 : ((i0 == 2) ? t2 : t3));
+      o1 = (i1 == 0) ? t0 : ((i1 == 1) ? t1 : ((i1 == 2) ? t2 : t3));
+      o2 = (i2 == 0) ? t0 : ((i2 == 1) ? t1 : ((i2 == 2) ? t2 : t3));
+      k = __popc(mask);
+      s0 = o0; s1 = o1; s2 = o2;
+      n = k;
+    }
+    double nsq = len2(nv);
+    if (nsq < TINY2) {
+      info |= GJK_PENETRATING;
+      return 0.0;
+    }
+    if (sq - nsq <= 1.0e-15 * sq && it > 0) {
+      // no progress any more (float32 scan picked a near-tied vertex): converged to working precision
+      return sqrt(fmin(sq, nsq));
+    }
+    v = nv;
+    sq = nsq;
+  }
+  info |= GJK_ITERCAP;
+  return sqrt(sq);
+}
+
+}  // namespace urgym

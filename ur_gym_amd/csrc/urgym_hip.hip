@@ -1,0 +1,1019 @@
+// urgym_hip.hip — fused UR5e reach environment kernels for MI355X (gfx950) + the C-ABI of include/urgym.h.
+//
+// One workgroup = 64 environments x 5 waves (320 threads).  Wave w owns PyBullet link L = w + 2 (upper arm,
+// forearm, wrist 1..3) of each of the 64 environments of the group: lane e of wave w evaluates link L of env e.
+//
+//   P0  all threads stream the packed convex-hull vertex table (42.5 KB, float32) from L2 into LDS
+//   P1  every lane: joint update q += 0.1*pi*clip(a) (UR5.py:273-279), obstacle motion (reach.py:728-753 +
+//       pyb_setup.py:52-55), FK of the URDF chain up to its own link in float64, bounding-capsule culling of the
+//       table / track / self-collision pairs of pyb_setup.py:382-429 that involve its link (survivors -> LDS queue)
+//   P2  every lane: exact GJK distance hull(L) <-> obstacle cylinder (pyb_setup.py:439-456)  -> LDS
+//   P3  the (rare) queued hull<->box / hull<->hull pairs, one per lane across the whole group
+//   P4  wave 4 (which holds the end-effector frame): Euler read-out, pose distances, success / collision /
+//       reward (reach.py:221-236, 356-374, 764-785), lagged link_dist, state write-back, observation rows staged
+//       in LDS and written back coalesced by all waves
+//
+// Finished environments are appended to a device-side list; a second launch of the same kernel in RESET mode
+// re-samples them (counter-based Philox, rejection rules of reach.py:313-326 / 664-683) with no host round trip.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <new>
+#include <vector>
+
+#include "../../include/urgym.h"
+#include "../../data/ur5e_model.h"
+#include "urgym_device.h"
+
+using namespace urgym;
+
+namespace {
+
+constexpr int ENVS_PER_GROUP = 64;
+constexpr int WAVES = 5;
+constexpr int THREADS = ENVS_PER_GROUP * WAVES;
+constexpr int MAX_HULL_BLOCKS = (UR5E_NUM_HULL_VERTS + 3 * UR5E_NUM_HULLS) / 4 + 1;
+constexpr int QUEUE_CAP = ENVS_PER_GROUP * 19;
+
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2 };
+enum { Q_TABLE = 0, Q_TRACK = 1, Q_SELF = 2 };
+
+// Bullet collision margins: hull 0.001; cylinder r=0.05 -> 0.005; table 0.04; track 0.006;
+// Dyn target box half 0.025 -> 0.0025; Obs target sphere -> radius 0.02 around a point core.
+constexpr double M_HULL = 0.001;
+constexpr double CYL_R = 0.05, CYL_H = 0.4, M_CYL = 0.005;
+constexpr double TABLE_CX = 0.5, TABLE_CY = 0.0, TABLE_CZ = -0.58, TABLE_HX = 0.55, TABLE_HY = 0.9, TABLE_HZ = 0.46;
+constexpr double M_TABLE = 0.04;
+constexpr double TRACK_CX = 0.0, TRACK_CY = 0.0, TRACK_CZ = -0.06, TRACK_HX = 0.1, TRACK_HY = 0.55, TRACK_HZ = 0.06;
+constexpr double M_TRACK = 0.006;
+constexpr double TARGET_BOX_H = 0.025, M_TARGET_BOX = 0.0025, TARGET_SPHERE_R = 0.02;
+
+struct DevTables {
+  double joint_rot[6][9];
+  double joint_xyz[6][3];
+  double capsule[6][7];
+  int hull_blk_off[7];
+};
+__constant__ DevTables c_tab;
+
+struct KParams {
+  urgym_config cfg;
+  urgym_buffers buf;
+  const float* hull_table;  // packed 4-vertex blocks, MAX_HULL_BLOCKS * 12 floats
+  int hull_blocks;
+  int obs_dim, goal_dim;
+  uint32_t seed_lo, seed_hi;
+  int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
+  int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
+};
+
+__device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
+
+__device__ __forceinline__ ShapeDesc hull_desc(int link /*1..6*/) {
+  ShapeDesc s;
+  s.type = SH_HULL;
+  s.blk_off = c_tab.hull_blk_off[link - 1];
+  s.nblk = c_tab.hull_blk_off[link] - c_tab.hull_blk_off[link - 1];
+  s.hx = s.hy = s.hz = 0.0;
+  const double* c = c_tab.capsule[link - 1];
+  s.center = d3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]));
+  return s;
+}
+__device__ __forceinline__ ShapeDesc cyl_desc() {
+  ShapeDesc s;
+  s.type = SH_CYLZ; s.blk_off = 0; s.nblk = 0;
+  s.hx = s.hy = CYL_R - M_CYL; s.hz = 0.5 * CYL_H - M_CYL;
+  s.center = d3(0, 0, 0);
+  return s;
+}
+__device__ __forceinline__ ShapeDesc box_desc(double hx, double hy, double hz, double margin) {
+  ShapeDesc s;
+  s.type = SH_BOX; s.blk_off = 0; s.nblk = 0;
+  s.hx = hx - margin; s.hy = hy - margin; s.hz = hz - margin;
+  s.center = d3(0, 0, 0);
+  return s;
+}
+__device__ __forceinline__ ShapeDesc point_desc() {
+  ShapeDesc s;
+  s.type = SH_POINT; s.blk_off = 0; s.nblk = 0; s.hx = s.hy = s.hz = 0.0;
+  s.center = d3(0, 0, 0);
+  return s;
+}
+
+// one joint of the URDF chain: T <- T * [R_fix | xyz] * Rz(q)   (ur5e.urdf:232-279)
+__device__ __forceinline__ void fk_joint(X3& T, int k, double qk) {
+  const double* F = c_tab.joint_rot[k];
+  const double* o = c_tab.joint_xyz[k];
+  T.t = T.t + rot(T, d3(o[0], o[1], o[2]));
+  double s, c;
+  sincos(qk, &s, &c);
+  // G = F * Rz(q): columns 0,1 mix, column 2 unchanged
+  double g[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    g[i * 3 + 0] = F[i * 3 + 0] * c + F[i * 3 + 1] * s;
+    g[i * 3 + 1] = F[i * 3 + 1] * c - F[i * 3 + 0] * s;
+    g[i * 3 + 2] = F[i * 3 + 2];
+  }
+  double r[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[i * 3 + j] = fma(T.r[i * 3], g[j], fma(T.r[i * 3 + 1], g[3 + j], T.r[i * 3 + 2] * g[6 + j]));
+#pragma unroll
+  for (int i = 0; i < 9; i++) T.r[i] = r[i];
+}
+__device__ __forceinline__ X3 identity_x3() {
+  X3 T;
+  T.r[0] = 1; T.r[1] = 0; T.r[2] = 0; T.r[3] = 0; T.r[4] = 1; T.r[5] = 0; T.r[6] = 0; T.r[7] = 0; T.r[8] = 1;
+  T.t = d3(0, 0, 0);
+  return T;
+}
+
+// closest distance between two segments (Ericson RTCD §5.1.9)
+__device__ __forceinline__ double segseg_dist(D3 p1, D3 q1, D3 p2, D3 q2) {
+  D3 d1 = q1 - p1, d2 = q2 - p2, r = p1 - p2;
+  double a = dot(d1, d1), e = dot(d2, d2), f = dot(d2, r);
+  double s, t;
+  const double EPS = 1e-18;
+  if (a <= EPS && e <= EPS) return sqrt(len2(r));
+  if (a <= EPS) {
+    s = 0.0;
+    t = fmin(1.0, fmax(0.0, f / e));
+  } else {
+    double c = dot(d1, r);
+    if (e <= EPS) {
+      t = 0.0;
+      s = fmin(1.0, fmax(0.0, -c / a));
+    } else {
+      double b = dot(d1, d2), den = a * e - b * b;
+      s = den > 1e-30 ? fmin(1.0, fmax(0.0, (b * f - c * e) / den)) : 0.0;
+      t = (b * s + f) / e;
+      if (t < 0.0) { t = 0.0; s = fmin(1.0, fmax(0.0, -c / a)); }
+      else if (t > 1.0) { t = 1.0; s = fmin(1.0, fmax(0.0, (b - c) / a)); }
+    }
+  }
+  D3 c1 = p1 + d1 * s, c2 = p2 + d2 * t;
+  return sqrt(len2(c1 - c2));
+}
+// lower bound of the distance between segment (p,q) and an axis-aligned box (centre c, half h)
+__device__ __forceinline__ double seg_box_lower_bound(D3 p, D3 q, double cx, double cy, double cz, double hx, double hy, double hz) {
+  double gx = fmax(fmax((cx - hx) - fmax(p.x, q.x), fmin(p.x, q.x) - (cx + hx)), 0.0);
+  double gy = fmax(fmax((cy - hy) - fmax(p.y, q.y), fmin(p.y, q.y) - (cy + hy)), 0.0);
+  double gz = fmax(fmax((cz - hz) - fmax(p.z, q.z), fmin(p.z, q.z) - (cz + hz)), 0.0);
+  return sqrt(gx * gx + gy * gy + gz * gz);
+}
+
+// ReachDyn.set_velocity (reach.py:728-753): v = (end-start)/T; omega = axis*angle/T of dq = nearest(q_end)*q_start^-1
+__device__ void dyn_velocity(const double start[6], const double end[6], double T, double vel[6]) {
+  for (int i = 0; i < 3; i++) vel[i] = (end[i] - start[i]) / T;
+  Q4 q0 = quat_from_rpy(start[3], start[4], start[5]), q1 = quat_from_rpy(end[3], end[4], end[5]);
+  double dm = (q0.x - q1.x) * (q0.x - q1.x) + (q0.y - q1.y) * (q0.y - q1.y) + (q0.z - q1.z) * (q0.z - q1.z) + (q0.w - q1.w) * (q0.w - q1.w);
+  double dp = (q0.x + q1.x) * (q0.x + q1.x) + (q0.y + q1.y) * (q0.y + q1.y) + (q0.z + q1.z) * (q0.z + q1.z) + (q0.w + q1.w) * (q0.w + q1.w);
+  if (!(dm < dp)) { q1.x = -q1.x; q1.y = -q1.y; q1.z = -q1.z; q1.w = -q1.w; }
+  Q4 dq = qmul(q1, Q4{-q0.x, -q0.y, -q0.z, q0.w});
+  double w = fmin(1.0, fmax(-1.0, dq.w));
+  double angle = 2.0 * acos(w);
+  double s2 = 1.0 - dq.w * dq.w;
+  D3 axis = d3(1, 0, 0);
+  if (!(s2 < 10.0 * 2.220446049250313e-16)) {
+    double s = 1.0 / sqrt(s2);
+    axis = d3(dq.x * s, dq.y * s, dq.z * s);
+  }
+  vel[3] = axis.x * angle / T; vel[4] = axis.y * angle / T; vel[5] = axis.z * angle / T;
+}
+
+// one env step of the obstacle base: p += v*dt, R <- exp([w] dt) R  (20 Bullet sub-steps of a constant twist
+// compose to a single exponential; pyb_setup.py:52-55)
+__device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const double vel[6], double dt) {
+  pos[0] += vel[0] * dt; pos[1] += vel[1] * dt; pos[2] += vel[2] * dt;
+  D3 w = d3(vel[3], vel[4], vel[5]);
+  double ang = sqrt(len2(w));
+  if (ang > 0.0) {
+    double s, c;
+    sincos(0.5 * ang * dt, &s, &c);
+    double k = s / ang;
+    Q4 dq{w.x * k, w.y * k, w.z * k, c};
+    Q4 r = qmul(dq, q);
+    double nrm = 1.0 / sqrt(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w);
+    q = Q4{r.x * nrm, r.y * nrm, r.z * nrm, r.w * nrm};
+  }
+}
+
+// ---- RESET: one lane samples a new episode (reach.py:197-200, 313-326, 664-683; samplers utils.py:81-100)
+template <int KIND>
+__device__ void sample_episode(const KParams& P, lds_f4_ptr tab, int n, int& flags) {
+  const urgym_config& cfg = P.cfg;
+  const urgym_buffers& B = P.buf;
+  const int N = cfg.num_envs;
+  const double DEG = 3.141592653589793 / 180.0;
+  uint32_t episode = (uint32_t)B.episode_id[n];
+  double goal[6] = {0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
+  for (int attempt = 0;; attempt++) {
+    double u[20];
+#pragma unroll
+    for (int blk = 0; blk < 5; blk++) {
+      uint32_t o[4];
+      philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, (uint32_t)blk, o);
+      u[blk * 4 + 0] = u01(o[0]); u[blk * 4 + 1] = u01(o[1]); u[blk * 4 + 2] = u01(o[2]); u[blk * 4 + 3] = u01(o[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) goal[i] = cfg.goal_low[i] + (cfg.goal_high[i] - cfg.goal_low[i]) * u[i];
+    if (KIND != URGYM_ENV_OBS) {  // utils.sample_euler_constrained
+      goal[3] = (-90.0 + (-180.0 - -90.0) * u[3]) * DEG;
+      goal[4] = 0.0 * DEG;
+      goal[5] = (0.0 + (-180.0 - 0.0) * u[4]) * DEG;
+    }
+    if (KIND == URGYM_ENV_ORI) break;
+#pragma unroll
+    for (int i = 0; i < 3; i++) st[i] = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * u[5 + i];
+    {  // utils.sample_euler_obstacle
+      double roll = (u[8] < 0.5) ? (-30.0 + (-150.0 - -30.0) * u[9]) : (30.0 + (150.0 - 30.0) * u[9]);
+      double pitch = (roll < -90.0 || roll > 90.0) ? (-30.0 + (-150.0 - -30.0) * u[10]) : (30.0 + (150.0 - 30.0) * u[10]);
+      st[3] = roll * DEG; st[4] = pitch * DEG; st[5] = 0.0 * DEG;
+    }
+    bool fail = false;
+    // target <-> obstacle clearance (pyb_setup.py:431-437): Obs = sphere r 0.02 vs obstacle at its pose (reach.py:316-322);
+    // Dyn = box half 0.025 at the goal pose vs obstacle at its END pose (reach.py:668-675)
+    ShapeDesc ta;
+    X3 Tt = identity_x3(), To;
+    double msum;
+    if (KIND == URGYM_ENV_OBS) {
+      ta = point_desc();
+      msum = TARGET_SPHERE_R + M_CYL;
+      quat_to_rot(quat_from_rpy(st[3], st[4], st[5]), To.r);
+      To.t = d3(st[0], st[1], st[2]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; i++) en[i] = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * u[11 + i];
+      double roll = (u[14] < 0.5) ? (-30.0 + (-150.0 - -30.0) * u[15]) : (30.0 + (150.0 - 30.0) * u[15]);
+      double pitch = (roll < -90.0 || roll > 90.0) ? (-30.0 + (-150.0 - -30.0) * u[16]) : (30.0 + (150.0 - 30.0) * u[16]);
+      en[3] = roll * DEG; en[4] = pitch * DEG; en[5] = 0.0 * DEG;
+      double dx = en[0] - st[0], dy = en[1] - st[1], dz = en[2] - st[2];
+      fail = sqrt(dx * dx + dy * dy + dz * dz) < cfg.min_travel;
+      ta = box_desc(TARGET_BOX_H, TARGET_BOX_H, TARGET_BOX_H, M_TARGET_BOX);
+      msum = M_TARGET_BOX + M_CYL;
+      quat_to_rot(quat_from_rpy(en[3], en[4], en[5]), To.r);
+      To.t = d3(en[0], en[1], en[2]);
+      quat_to_rot(quat_from_rpy(goal[3], goal[4], goal[5]), Tt.r);
+    }
+    if (!fail) {
+      Tt.t = d3(goal[0], goal[1], goal[2]);
+      int info;
+      double core = gjk_core_distance(tab, ta, rel(To, Tt), cyl_desc(), 1e30, info);
+      double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
+      fail = dist < cfg.target_clearance;
+    }
+    if (!fail) break;
+    if (attempt + 1 >= cfg.max_reset_tries) {
+      flags |= URGYM_STATUS_RESET_EXHAUSTED;
+      break;
+    }
+  }
+  for (int i = 0; i < 6; i++) SOA(B.goal, i, n, N) = goal[i];
+  if (KIND != URGYM_ENV_ORI) {
+    for (int i = 0; i < 6; i++) { SOA(B.obst_start, i, n, N) = st[i]; SOA(B.obst_end, i, n, N) = en[i]; }
+  }
+  for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = cfg.neutral_q[i];
+  B.episode_id[n] = (int32_t)(episode + 1);
+}
+
+template <int KIND, int MODE>
+__global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const float* __restrict__ actions) {
+  __shared__ float4 s_hull[MAX_HULL_BLOCKS * 3];
+  __shared__ double s_dist[WAVES][ENVS_PER_GROUP];
+  __shared__ double s_q[6][ENVS_PER_GROUP];
+  __shared__ double s_obst[7][ENVS_PER_GROUP];
+  __shared__ uint32_t s_queue[QUEUE_CAP];
+  __shared__ int s_qcount;
+  __shared__ int s_coll[ENVS_PER_GROUP];
+  __shared__ int s_flags[ENVS_PER_GROUP];
+  float* const s_out = reinterpret_cast<float*>(s_hull);  // observation staging reuses the hull table after P3
+  static_assert(sizeof(float) * ENVS_PER_GROUP * 47 <= sizeof(float4) * MAX_HULL_BLOCKS * 3, "staging must fit");
+
+  const urgym_config& cfg = P.cfg;
+  const urgym_buffers& B = P.buf;
+  const int N = cfg.num_envs;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = wv + 2;  // PyBullet link index owned by this wave
+  const int OD = P.obs_dim, GD = P.goal_dim;
+  constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
+
+  // ---- which environment does this lane work on?
+  const int idx = blockIdx.x * ENVS_PER_GROUP + lane;
+  int n;
+  bool active;
+  int list_count = 0;
+  if (MODE == MODE_STEP) {
+    n = idx;
+    active = idx < N;
+  } else {
+    list_count = B.done_count[P.pp];
+    if (blockIdx.x * ENVS_PER_GROUP >= list_count) return;  // uniform for the whole group
+    active = idx < list_count;
+    n = active ? B.done_list[idx] : 0;
+  }
+  if (tid == 0) s_qcount = 0;
+  if (tid < ENVS_PER_GROUP) { s_coll[tid] = 0; s_flags[tid] = 0; }
+
+  // ---- P0: hull table -> LDS
+  {
+    const float4* src = reinterpret_cast<const float4*>(P.hull_table);
+    const int total = P.hull_blocks * 3;
+    for (int i = tid; i < total; i += THREADS) s_hull[i] = src[i];
+  }
+  lds_f4_ptr tab = (lds_f4_ptr)(s_hull);
+  __syncthreads();
+
+  if (MODE == MODE_RESET) {
+    if (wv == 0 && active) {
+      int flags = 0;
+      sample_episode<KIND>(P, tab, n, flags);
+      if (flags) atomicOr(&s_flags[lane], flags);
+    }
+    __threadfence_block();
+    __syncthreads();  // the sampled goal / obstacle (global memory) is visible to the other waves of this group
+  }
+
+  // ---- P1: state, joint update, obstacle motion, FK to link L, culling, pose of hull L in the obstacle frame
+  X3 Trel = identity_x3();
+  if (active) {
+    double q[6];
+    for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
+    if (MODE == MODE_STEP) {
+      for (int i = 0; i < 6; i++) {
+        float a = actions[(size_t)n * 6 + i];
+        a = fminf(1.0f, fmaxf(-1.0f, a));
+        float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
+        float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
+        q[i] += (double)t2;
+      }
+    }
+    double opos[3] = {0, 0, 0};
+    Q4 oq{0, 0, 0, 1};
+    if (HAS_OBST) {
+      if (MODE == MODE_STEP) {
+        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
+        oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
+        if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
+          double ovel[6];
+          for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
+          integrate_obstacle(opos, oq, ovel, cfg.dt);
+        }
+      } else {
+        // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
+        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
+        oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
+      }
+    }
+    if (wv == WAVES - 1) {
+      for (int i = 0; i < 6; i++) s_q[i][lane] = q[i];
+      s_obst[0][lane] = opos[0]; s_obst[1][lane] = opos[1]; s_obst[2][lane] = opos[2];
+      s_obst[3][lane] = oq.x; s_obst[4][lane] = oq.y; s_obst[5][lane] = oq.z; s_obst[6][lane] = oq.w;
+    }
+    // FK up to link L, remembering the world capsules of links 1..3 for the self-collision culling
+    X3 TL = identity_x3();
+    D3 capA0[3], capA1[3];
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      if (k < L) {
+        fk_joint(TL, k, q[k]);
+        if (k < 3) {
+          const double* c = c_tab.capsule[k];
+          capA0[k] = apply(TL, d3(c[0], c[1], c[2]));
+          capA1[k] = apply(TL, d3(c[3], c[4], c[5]));
+        }
+      }
+    }
+    if (cfg.check_collision && MODE != MODE_RESET) {
+      const double* c = c_tab.capsule[L - 1];
+      D3 b0 = apply(TL, d3(c[0], c[1], c[2])), b1 = apply(TL, d3(c[3], c[4], c[5]));
+      double rb = c[6];
+      const double lim = cfg.collision_margin + 1e-6;
+      if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim) {
+        int slot = atomicAdd(&s_qcount, 1);
+        s_queue[slot] = (uint32_t)lane | (Q_TABLE << 6) | ((uint32_t)L << 8);
+      }
+      if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim) {
+        int slot = atomicAdd(&s_qcount, 1);
+        s_queue[slot] = (uint32_t)lane | (Q_TRACK << 6) | ((uint32_t)L << 8);
+      }
+      // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6) -> handled by the wave of link B
+#pragma unroll
+      for (int A = 1; A <= 3; A++) {
+        if (A <= L - 2) {
+          double ra = c_tab.capsule[A - 1][6];
+          if (segseg_dist(capA0[A - 1], capA1[A - 1], b0, b1) - ra - rb <= lim) {
+            int slot = atomicAdd(&s_qcount, 1);
+            s_queue[slot] = (uint32_t)lane | (Q_SELF << 6) | ((uint32_t)L << 8) | ((uint32_t)A << 11);
+          }
+        }
+      }
+    }
+    if (HAS_OBST) {
+      X3 To;
+      quat_to_rot(oq, To.r);
+      To.t = d3(opos[0], opos[1], opos[2]);
+      Trel = rel(To, TL);
+    }
+  }
+  __syncthreads();
+
+  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined GJK body.
+  //   round 0  (envs with an obstacle): lane <-> exact distance hull(L) <-> obstacle cylinder (pyb_setup.py:439-456;
+  //            it also decides the obstacle part of check_collision, pyb_setup.py:397-405)
+  //   round 1+ : the (rare) table / track / self pairs that survived the capsule culling, one per lane across the
+  //            whole group; boolean "closer than the collision margin?" with early exit
+  {
+    const int qn = s_qcount;  // complete since the barrier after P1
+    const int first_q = HAS_OBST ? 1 : 0;
+    const int nrounds = first_q + (qn + THREADS - 1) / THREADS;
+    for (int round = 0; round < nrounds; round++) {
+      bool have;
+      ShapeDesc sa, sb;
+      X3 Tab;
+      double msum, stop;
+      int e = lane;
+      const bool obst_round = HAS_OBST && round == 0;
+      if (obst_round) {
+        have = active;
+        sa = hull_desc(L);
+        sb = cyl_desc();
+        Tab = Trel;
+        msum = M_HULL + M_CYL;
+        stop = 1e30;
+      } else {
+        const int it = (round - first_q) * THREADS + tid;
+        have = it < qn;
+        const uint32_t item = have ? s_queue[it] : 0u;
+        e = item & 63;
+        const int kind = (item >> 6) & 3, lb = (item >> 8) & 7, la = (item >> 11) & 7;
+        X3 T = identity_x3(), TA = identity_x3();
+        for (int k = 0; k < 6; k++) {
+          if (have && k < lb) {
+            fk_joint(T, k, s_q[k][e]);
+            if (k + 1 == la) TA = T;
+          }
+        }
+        if (kind == Q_SELF) {
+          sa = hull_desc(la < 1 ? 1 : la);
+          sb = hull_desc(lb < 1 ? 1 : lb);
+          Tab = rel(T, TA);
+          msum = M_HULL + M_HULL;
+        } else {
+          const bool tbl = (kind == Q_TABLE);
+          sa = hull_desc(lb < 1 ? 1 : lb);
+          sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
+          Tab = T;
+          Tab.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+          msum = M_HULL + (tbl ? M_TABLE : M_TRACK);
+        }
+        stop = cfg.collision_margin + msum;
+      }
+      if (have) {
+        int info;
+        const double core = gjk_core_distance(tab, sa, Tab, sb, stop, info);
+        if (obst_round) {
+          double dist = core - msum;
+          if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[lane], URGYM_STATUS_PENETRATION); }
+          if (info & GJK_ITERCAP) atomicOr(&s_flags[lane], URGYM_STATUS_GJK_ITER);
+          s_dist[wv][lane] = dist;
+        } else {
+          const bool hit = (info & GJK_PENETRATING) || (!(info & GJK_SEPARATED) && (core - msum) <= cfg.collision_margin);
+          if (hit) atomicOr(&s_coll[e], 1);
+        }
+      } else if (obst_round) {
+        s_dist[wv][lane] = 1e30;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: wave 4 re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
+  if (wv == WAVES - 1 && active) {
+    double q[6];
+    for (int i = 0; i < 6; i++) q[i] = s_q[i][lane];
+    X3 TE = identity_x3();
+#pragma unroll
+    for (int k = 0; k < 6; k++) fk_joint(TE, k, q[k]);
+    double opos[3] = {s_obst[0][lane], s_obst[1][lane], s_obst[2][lane]};
+    Q4 oq{s_obst[3][lane], s_obst[4][lane], s_obst[5][lane], s_obst[6][lane]};
+    const int step_count = B.step_count[n];
+    Q4 eq = rot_to_quat(TE.r);
+    double er, ep, ey;
+    rpy_from_quat(eq, er, ep, ey);
+    float* row = &s_out[lane * 47];
+    float ach[6];
+    ach[0] = (float)TE.t.x; ach[1] = (float)TE.t.y; ach[2] = (float)TE.t.z;
+    ach[3] = (float)er; ach[4] = (float)ep; ach[5] = (float)ey;
+    double goal[6];
+    for (int i = 0; i < 6; i++) goal[i] = SOA(B.goal, i, n, N);
+    double ld_old[5] = {0, 0, 0, 0, 0}, ld_new[5] = {0, 0, 0, 0, 0};
+    bool coll = s_coll[lane] != 0;
+    if (HAS_OBST) {
+      for (int i = 0; i < 5; i++) {
+        ld_new[i] = s_dist[i][lane];
+        if (MODE == MODE_STEP) ld_old[i] = SOA(B.link_dist, i, n, N);
+        if (cfg.check_collision && ld_new[i] <= cfg.collision_margin) coll = true;
+      }
+    }
+    // velocity slot of the Dyn observation (reach.py:657): STEP -> the velocity applied in this step; RESET/REFRESH ->
+    // the stale ReachDyn.velocity of the previous step, which still sits in the observation buffer
+    double vobs[6] = {0, 0, 0, 0, 0, 0};
+    if (KIND == URGYM_ENV_DYN) {
+      if (MODE == MODE_STEP) {
+        if (step_count < cfg.dyn_motion_steps)
+          for (int i = 0; i < 6; i++) vobs[i] = SOA(B.obst_vel, i, n, N);
+      } else {
+        for (int i = 0; i < 6; i++) vobs[i] = (double)B.observation[(size_t)n * OD + 24 + i];
+      }
+    }
+    if (MODE == MODE_RESET && P.copy_final) {
+      for (int i = 0; i < OD; i++) B.final_observation[(size_t)n * OD + i] = B.observation[(size_t)n * OD + i];
+      for (int i = 0; i < GD; i++) {
+        B.final_achieved_goal[(size_t)n * GD + i] = B.achieved_goal[(size_t)n * GD + i];
+        B.final_desired_goal[(size_t)n * GD + i] = B.desired_goal[(size_t)n * GD + i];
+      }
+    }
+    // observation row (core.py:252-261; UR5.py:320-325; reach.py:189, 307-308, 653-657)
+    const double* ld_obs = (MODE == MODE_STEP) ? ld_old : ld_new;  // step(): link_dist lags one step (core.py:311 vs 316)
+    int p = 0;
+    for (int i = 0; i < 6; i++) row[p++] = ach[i];
+    for (int i = 0; i < 6; i++) row[p++] = (float)q[i];
+    if (KIND == URGYM_ENV_ORI) {
+      for (int i = 0; i < 6; i++) row[p++] = (float)goal[i];
+    } else if (KIND == URGYM_ENV_OBS) {
+      for (int i = 0; i < 3; i++) row[p++] = (float)goal[i];
+      for (int i = 0; i < 6; i++) row[p++] = (float)SOA(B.obst_start, i, n, N);
+      for (int i = 0; i < 5; i++) row[p++] = (float)ld_obs[i];
+    } else {
+      for (int i = 0; i < 6; i++) row[p++] = (float)goal[i];
+      for (int i = 0; i < 3; i++) row[p++] = (float)opos[i];
+      double r_, p_, y_;
+      rpy_from_quat(oq, r_, p_, y_);
+      row[p++] = (float)r_; row[p++] = (float)p_; row[p++] = (float)y_;
+      for (int i = 0; i < 6; i++) row[p++] = (float)vobs[i];
+      for (int i = 0; i < 5; i++) row[p++] = (float)ld_obs[i];
+    }
+    for (int i = 0; i < GD; i++) { row[OD + i] = ach[i]; row[OD + GD + i] = (float)goal[i]; }
+
+    // is_success on the float32 achieved goal vs the float64 goal (reach.py:212-215, 348-350, 755-758)
+    double dx = (double)ach[0] - goal[0], dy = (double)ach[1] - goal[1], dz = (double)ach[2] - goal[2];
+    double d = sqrt(dx * dx + dy * dy + dz * dz);
+    double th = 0.0;
+    bool succ;
+    if (KIND == URGYM_ENV_OBS) {
+      succ = d < cfg.distance_threshold;
+    } else {
+      double a3[3] = {(double)ach[3], (double)ach[4], (double)ach[5]};
+      th = angular_distance(a3, goal + 3);
+      succ = (d < cfg.distance_threshold) && (th < cfg.ori_threshold);
+    }
+    int flags = s_flags[lane];
+    if (MODE == MODE_STEP) {
+      bool terminated = succ || coll;                 // core.py:313
+      bool info_success = terminated ? !coll : false; // core.py:315
+      double reward = 0.0;
+      bool update_ld = false;
+      if (KIND == URGYM_ENV_ORI) {  // reach.py:221-236
+        reward += succ ? cfg.w_success : 0.0;
+        reward += d * cfg.w_distance;
+        reward += th * cfg.w_orientation;
+        reward += coll ? cfg.w_collision : 0.0;
+      } else if (KIND == URGYM_ENV_OBS) {  // reach.py:356-374
+        reward += succ ? cfg.w_success : 0.0;
+        reward += coll ? cfg.w_collision : 0.0;
+        reward += cfg.w_distance * d;
+        double sum = 0.0;
+        for (int i = 0; i < 5; i++) sum += (ld_new[i] < cfg.near_threshold) ? cfg.w_link[i] * (ld_new[i] - ld_old[i]) : 0.0;
+        reward += sum;
+        update_ld = true;
+      } else {  // reach.py:764-785
+        if (coll) reward = cfg.w_collision;
+        else if (succ) reward = cfg.w_success;
+        else {
+          reward += cfg.w_distance * d;
+          reward += cfg.w_orientation * th;
+          double sum = 0.0;
+          for (int i = 0; i < 5; i++) sum += (ld_new[i] < cfg.near_threshold) ? cfg.w_link[i] * (ld_new[i] - ld_old[i]) : 0.0;
+          reward += sum;
+          update_ld = true;
+        }
+      }
+      if (reward != reward) flags |= URGYM_STATUS_NAN;
+      int sc = step_count + 1;
+      bool truncated = sc >= cfg.max_episode_steps;  // TimeLimit (UR_gym/__init__.py:41)
+      for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = q[i];
+      B.step_count[n] = sc;
+      if (KIND == URGYM_ENV_DYN) {
+        for (int i = 0; i < 3; i++) SOA(B.obst_pos, i, n, N) = opos[i];
+        SOA(B.obst_quat, 0, n, N) = oq.x; SOA(B.obst_quat, 1, n, N) = oq.y; SOA(B.obst_quat, 2, n, N) = oq.z; SOA(B.obst_quat, 3, n, N) = oq.w;
+      }
+      if (update_ld)
+        for (int i = 0; i < 5; i++) SOA(B.link_dist, i, n, N) = ld_new[i];
+      B.reward[n] = (float)reward;
+      B.terminated[n] = terminated ? 1 : 0;
+      B.truncated[n] = truncated ? 1 : 0;
+      B.is_success[n] = info_success ? 1 : 0;
+      B.collision[n] = coll ? 1 : 0;
+      if (cfg.auto_reset && (terminated || truncated)) {
+        int slot = atomicAdd(&B.done_count[P.pp], 1);
+        B.done_list[slot] = n;
+      }
+    } else {
+      // reset / refresh: fresh link_dist == last_dist (reach.py:324-325, 680-681, 711-713), obstacle pose + velocity
+      if (HAS_OBST) {
+        for (int i = 0; i < 3; i++) SOA(B.obst_pos, i, n, N) = opos[i];
+        SOA(B.obst_quat, 0, n, N) = oq.x; SOA(B.obst_quat, 1, n, N) = oq.y; SOA(B.obst_quat, 2, n, N) = oq.z; SOA(B.obst_quat, 3, n, N) = oq.w;
+        for (int i = 0; i < 5; i++) SOA(B.link_dist, i, n, N) = ld_new[i];
+        double vel[6] = {0, 0, 0, 0, 0, 0};
+        if (KIND == URGYM_ENV_DYN) {
+          double st[6], en[6];
+          for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); }
+          dyn_velocity(st, en, cfg.dyn_time_duration, vel);
+        }
+        for (int i = 0; i < 6; i++) SOA(B.obst_vel, i, n, N) = vel[i];
+      }
+      if (MODE == MODE_RESET) {
+        B.step_count[n] = 0;
+        if (coll) flags |= URGYM_STATUS_RESET_COLLISION;
+        if (!P.copy_final) {
+          B.reward[n] = 0.f; B.terminated[n] = 0; B.truncated[n] = 0;
+          B.is_success[n] = succ ? 1 : 0;
+          B.collision[n] = coll ? 1 : 0;
+        }
+      } else {
+        B.is_success[n] = succ ? 1 : 0;
+        B.collision[n] = coll ? 1 : 0;
+      }
+    }
+    if (flags) atomicOr(&B.status[n], flags);
+  }
+  __syncthreads();
+
+  // ---- write-back of the observation rows staged in LDS (coalesced for STEP: the group's rows are contiguous)
+  if (MODE == MODE_STEP) {
+    const int base = blockIdx.x * ENVS_PER_GROUP;
+    const int cnt = min(ENVS_PER_GROUP, N - base);
+    for (int i = tid; i < cnt * OD; i += THREADS) B.observation[(size_t)base * OD + i] = s_out[(i / OD) * 47 + (i % OD)];
+    for (int i = tid; i < cnt * GD; i += THREADS) {
+      B.achieved_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + (i % GD)];
+      B.desired_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + GD + (i % GD)];
+    }
+    if (blockIdx.x == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
+  } else {
+    const int cnt = min(ENVS_PER_GROUP, list_count - (int)blockIdx.x * ENVS_PER_GROUP);
+    for (int i = tid; i < cnt * OD; i += THREADS) {
+      int e = i / OD;
+      int ne = B.done_list[blockIdx.x * ENVS_PER_GROUP + e];
+      B.observation[(size_t)ne * OD + (i % OD)] = s_out[e * 47 + (i % OD)];
+    }
+    for (int i = tid; i < cnt * GD; i += THREADS) {
+      int e = i / GD;
+      int ne = B.done_list[blockIdx.x * ENVS_PER_GROUP + e];
+      B.achieved_goal[(size_t)ne * GD + (i % GD)] = s_out[e * 47 + OD + (i % GD)];
+      B.desired_goal[(size_t)ne * GD + (i % GD)] = s_out[e * 47 + OD + GD + (i % GD)];
+    }
+  }
+}
+
+// compaction of an explicit reset / refresh mask into done_list (mask == nullptr: every env)
+__global__ void build_list_kernel(const uint8_t* mask, int N, int* list, int* count) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (mask == nullptr) {
+    list[i] = i;
+    if (i == 0) *count = N;
+  } else if (mask[i]) {
+    int slot = atomicAdd(count, 1);
+    list[slot] = i;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------- host side
+struct Handle {
+  urgym_config cfg;
+  urgym_buffers buf;
+  bool bound = false;
+  int device = 0;
+  int obs_dim = 0, goal_dim = 0;
+  float* d_hull = nullptr;
+  int hull_blocks = 0;
+  uint64_t seed = 0;
+  int pp = 0;
+  char err[512] = {0};
+  // timing
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // pairs: [2i] start, [2i+1] stop ; kind in ev_kind
+  std::vector<int> ev_kind;    // 0 = step kernel, 1 = reset kernel
+  size_t ev_used = 0;
+};
+thread_local char g_err[512] = {0};
+
+int fail(Handle* h, int code, const char* what, hipError_t e = hipSuccess) {
+  char* dst = h ? h->err : g_err;
+  if (e != hipSuccess)
+    snprintf(dst, 512, "%s: %s", what, hipGetErrorString(e));
+  else
+    snprintf(dst, 512, "%s", what);
+  return code;
+}
+#define HIP_TRY(h, call)                                              \
+  do {                                                                \
+    hipError_t _e = (call);                                           \
+    if (_e != hipSuccess) return fail(h, URGYM_ERR_HIP, #call, _e);   \
+  } while (0)
+
+void fill_default(int env_kind, int num_envs, urgym_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->env_kind = env_kind;
+  c->num_envs = num_envs;
+  c->max_episode_steps = 100;  // UR_gym/__init__.py:41
+  c->auto_reset = 1;
+  c->check_collision = 1;
+  c->max_reset_tries = 4096;
+  c->dyn_motion_steps = 25;    // reach.py:735
+  c->action_scale = M_PI * 0.1;
+  c->dt = 20.0 / 500.0;        // pyb_setup.py:25,40
+  c->distance_threshold = 0.05;
+  c->ori_threshold = 0.0873;
+  c->w_collision = -500;
+  c->w_success = 200;
+  c->near_threshold = 0.2;
+  c->collision_margin = 0.01;
+  c->target_clearance = 0.1;
+  c->min_travel = 1.0;
+  c->dyn_time_duration = 2.0;
+  const double neutral[6] = {0.0, -1.5708, 0.0, -1.5708, 0.0, 0.0};  // UR5.py:262
+  for (int i = 0; i < 6; i++) c->neutral_q[i] = neutral[i];
+  if (env_kind == URGYM_ENV_ORI) {  // reach.py:148-157
+    c->w_distance = -70; c->w_orientation = -30;
+    const double gl[3] = {0.3, -0.5, 0.0}, gh[3] = {0.75, 0.5, 0.2};
+    for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; }
+  } else if (env_kind == URGYM_ENV_OBS) {  // reach.py:246-256
+    c->w_distance = -100; c->w_orientation = 0;
+    const double gl[3] = {0.3, -0.5, -0.1}, gh[3] = {0.75, 0.5, 0.2}, ol[3] = {0.5, -0.5, 0.25}, oh[3] = {1.0, 0.5, 0.55};
+    for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; c->obst_low[i] = ol[i]; c->obst_high[i] = oh[i]; }
+    for (int i = 0; i < 5; i++) c->w_link[i] = 100.0;
+  } else {  // reach.py:584-598
+    c->w_distance = -70; c->w_orientation = -30;
+    const double gl[3] = {0.4, -0.5, 0.0}, gh[3] = {0.75, 0.5, 0.2}, ol[3] = {0.5, -0.8, 0.25}, oh[3] = {1.2, 0.8, 0.75};
+    for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; c->obst_low[i] = ol[i]; c->obst_high[i] = oh[i]; }
+    const double lw[5] = {8, 2.4, 1.2, 1.2, 0.2};
+    double sum = 0;
+    for (int i = 0; i < 5; i++) sum += lw[i];
+    for (int i = 0; i < 5; i++) c->w_link[i] = lw[i] / sum * 50;
+  }
+}
+
+KParams make_params(Handle* h, int copy_final) {
+  KParams P;
+  P.cfg = h->cfg;
+  P.buf = h->buf;
+  P.hull_table = h->d_hull;
+  P.hull_blocks = h->hull_blocks;
+  P.obs_dim = h->obs_dim;
+  P.goal_dim = h->goal_dim;
+  P.seed_lo = (uint32_t)h->seed;
+  P.seed_hi = (uint32_t)(h->seed >> 32);
+  P.pp = h->pp;
+  P.copy_final = copy_final;
+  return P;
+}
+
+template <int MODE>
+void launch_mode(Handle* h, const KParams& P, const float* actions, int groups, hipStream_t s) {
+  dim3 grid(groups), block(THREADS);
+  switch (h->cfg.env_kind) {
+    case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
+    case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE>), grid, block, 0, s, P, actions); break;
+    default: hipLaunchKernelGGL((env_kernel<URGYM_ENV_DYN, MODE>), grid, block, 0, s, P, actions); break;
+  }
+}
+
+int time_begin(Handle* h, int kind, hipStream_t s) {
+  if (!h->timing || h->ev_used >= 65536) return -1;
+  if (h->ev_used + 2 > h->ev.size()) {
+    for (int i = 0; i < 2; i++) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return -1;
+      h->ev.push_back(e);
+    }
+    h->ev_kind.push_back(kind);
+  }
+  h->ev_kind[h->ev_used / 2] = kind;
+  hipEventRecord(h->ev[h->ev_used], s);
+  return (int)h->ev_used;
+}
+void time_end(Handle* h, int slot, hipStream_t s) {
+  if (slot < 0) return;
+  hipEventRecord(h->ev[slot + 1], s);
+  h->ev_used = slot + 2;
+}
+
+int check_bound(Handle* h) {
+  if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
+  if (!h->bound) return fail(h, URGYM_ERR_STATE, "urgym_bind() has not been called");
+  return URGYM_OK;
+}
+
+int do_step(Handle* h, const float* actions, hipStream_t s) {
+  const int N = h->cfg.num_envs;
+  const int groups = (N + ENVS_PER_GROUP - 1) / ENVS_PER_GROUP;
+  KParams P = make_params(h, 1);
+  int slot = time_begin(h, 0, s);
+  launch_mode<MODE_STEP>(h, P, actions, groups, s);
+  time_end(h, slot, s);
+  if (h->cfg.auto_reset) {
+    slot = time_begin(h, 1, s);
+    launch_mode<MODE_RESET>(h, P, nullptr, groups, s);
+    time_end(h, slot, s);
+  }
+  h->pp ^= 1;
+  HIP_TRY(h, hipGetLastError());
+  return URGYM_OK;
+}
+
+int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
+  const int N = h->cfg.num_envs;
+  const int groups = (N + ENVS_PER_GROUP - 1) / ENVS_PER_GROUP;
+  HIP_TRY(h, hipMemsetAsync(h->buf.done_count + h->pp, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(build_list_kernel, dim3((N + 255) / 256), dim3(256), 0, s, mask, N, h->buf.done_list, h->buf.done_count + h->pp);
+  KParams P = make_params(h, 0);
+  if (mode == MODE_RESET)
+    launch_mode<MODE_RESET>(h, P, nullptr, groups, s);
+  else
+    launch_mode<MODE_REFRESH>(h, P, nullptr, groups, s);
+  // leave the consumed counter zeroed so the next step can append to either slot
+  HIP_TRY(h, hipMemsetAsync(h->buf.done_count, 0, 2 * sizeof(int32_t), s));
+  HIP_TRY(h, hipGetLastError());
+  return URGYM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int urgym_abi_version(void) { return URGYM_ABI_VERSION; }
+
+int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg) {
+  if (!cfg || env_kind < 0 || env_kind > 2 || num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_config_default: bad argument");
+  fill_default(env_kind, num_envs, cfg);
+  return URGYM_OK;
+}
+
+int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim) {
+  if (env_kind < 0 || env_kind > 2 || !obs_dim || !goal_dim) return fail(nullptr, URGYM_ERR_ARG, "urgym_obs_dims: bad argument");
+  *obs_dim = env_kind == URGYM_ENV_ORI ? 18 : (env_kind == URGYM_ENV_OBS ? 26 : 35);
+  *goal_dim = env_kind == URGYM_ENV_OBS ? 3 : 6;
+  return URGYM_OK;
+}
+
+int urgym_create(const urgym_config* cfg, int device, void** handle) {
+  if (!cfg || !handle) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: null argument");
+  if (cfg->env_kind < 0 || cfg->env_kind > 2 || cfg->num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad env_kind/num_envs");
+  if (device < 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: this library has no CPU path; device must be a HIP ordinal >= 0");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || device >= count) return fail(nullptr, URGYM_ERR_HIP, "urgym_create: HIP device not available", e);
+  HIP_TRY(nullptr, hipSetDevice(device));
+  Handle* h = new (std::nothrow) Handle();
+  if (!h) return fail(nullptr, URGYM_ERR_STATE, "out of memory");
+  h->cfg = *cfg;
+  h->device = device;
+  urgym_obs_dims(cfg->env_kind, &h->obs_dim, &h->goal_dim);
+  // constant tables
+  DevTables t;
+  memcpy(t.joint_rot, UR5E_JOINT_ROT, sizeof(t.joint_rot));
+  memcpy(t.joint_xyz, UR5E_JOINT_XYZ, sizeof(t.joint_xyz));
+  memcpy(t.capsule, UR5E_CAPSULE, sizeof(t.capsule));
+  std::vector<float> packed((size_t)MAX_HULL_BLOCKS * 12, 0.f);
+  int blk = 0;
+  for (int hidx = 0; hidx < 6; hidx++) {
+    t.hull_blk_off[hidx] = blk;
+    int v0 = UR5E_HULL_OFFSET[hidx], v1 = UR5E_HULL_OFFSET[hidx + 1];
+    for (int v = v0; v < v1; v += 4, blk++) {
+      for (int j = 0; j < 4; j++) {
+        int vi = v + j < v1 ? v + j : v1 - 1;  // pad the last block by repeating the last vertex
+        packed[(size_t)blk * 12 + 0 + j] = (float)UR5E_HULL_VERTS[vi][0];
+        packed[(size_t)blk * 12 + 4 + j] = (float)UR5E_HULL_VERTS[vi][1];
+        packed[(size_t)blk * 12 + 8 + j] = (float)UR5E_HULL_VERTS[vi][2];
+      }
+    }
+  }
+  t.hull_blk_off[6] = blk;
+  h->hull_blocks = blk;
+  if (blk > MAX_HULL_BLOCKS) { delete h; return fail(nullptr, URGYM_ERR_STATE, "hull table larger than the LDS budget"); }
+  e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
+  if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpyToSymbol(c_tab)", e); }
+  e = hipMalloc(&h->d_hull, packed.size() * sizeof(float));
+  if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMalloc(hull table)", e); }
+  e = hipMemcpy(h->d_hull, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(h->d_hull); delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpy(hull table)", e); }
+  *handle = h;
+  return URGYM_OK;
+}
+
+int urgym_destroy(void* handle) {
+  Handle* h = (Handle*)handle;
+  if (!h) return URGYM_OK;
+  hipSetDevice(h->device);
+  for (auto e : h->ev) hipEventDestroy(e);
+  if (h->d_hull) hipFree(h->d_hull);
+  delete h;
+  return URGYM_OK;
+}
+
+int urgym_bind(void* handle, const urgym_buffers* b) {
+  Handle* h = (Handle*)handle;
+  if (!h || !b) return fail(h, URGYM_ERR_ARG, "urgym_bind: null argument");
+  const bool obst = h->cfg.env_kind != URGYM_ENV_ORI;
+  if (!b->q || !b->goal || !b->step_count || !b->episode_id || !b->observation || !b->achieved_goal || !b->desired_goal ||
+      !b->reward || !b->terminated || !b->truncated || !b->is_success || !b->collision || !b->final_observation ||
+      !b->final_achieved_goal || !b->final_desired_goal || !b->status || !b->done_list || !b->done_count)
+    return fail(h, URGYM_ERR_ARG, "urgym_bind: a required buffer pointer is null");
+  if (obst && (!b->obst_start || !b->obst_end || !b->obst_pos || !b->obst_quat || !b->obst_vel || !b->link_dist))
+    return fail(h, URGYM_ERR_ARG, "urgym_bind: an obstacle buffer pointer is null");
+  h->buf = *b;
+  h->bound = true;
+  return URGYM_OK;
+}
+
+int urgym_reset(void* handle, const uint8_t* mask_dev, uint64_t seed, void* stream) {
+  Handle* h = (Handle*)handle;
+  int rc = check_bound(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (seed != UINT64_MAX) h->seed = seed;
+  return do_masked(h, mask_dev, MODE_RESET, (hipStream_t)stream);
+}
+
+int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream) {
+  Handle* h = (Handle*)handle;
+  int rc = check_bound(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipSetDevice(h->device));
+  return do_masked(h, mask_dev, MODE_REFRESH, (hipStream_t)stream);
+}
+
+int urgym_step(void* handle, const float* actions_dev, void* stream) {
+  Handle* h = (Handle*)handle;
+  int rc = check_bound(h);
+  if (rc) return rc;
+  if (!actions_dev) return fail(h, URGYM_ERR_ARG, "urgym_step: null actions");
+  HIP_TRY(h, hipSetDevice(h->device));
+  return do_step(h, actions_dev, (hipStream_t)stream);
+}
+
+int urgym_rollout(void* handle, const float* actions_dev, int num_steps, void* stream) {
+  Handle* h = (Handle*)handle;
+  int rc = check_bound(h);
+  if (rc) return rc;
+  if (!actions_dev || num_steps < 0) return fail(h, URGYM_ERR_ARG, "urgym_rollout: bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  for (int k = 0; k < num_steps; k++) {
+    rc = do_step(h, actions_dev + (size_t)k * h->cfg.num_envs * 6, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return URGYM_OK;
+}
+
+int urgym_enable_timing(void* handle, int enable) {
+  Handle* h = (Handle*)handle;
+  if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
+  h->timing = enable != 0;
+  h->ev_used = 0;
+  return URGYM_OK;
+}
+
+int urgym_query_timing(void* handle, double* step_us, double* reset_us, int* launches) {
+  Handle* h = (Handle*)handle;
+  if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
+  if (!h->timing) return fail(h, URGYM_ERR_STATE, "timing not enabled");
+  double acc[2] = {0, 0};
+  int cnt[2] = {0, 0};
+  for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+    HIP_TRY(h, hipEventSynchronize(h->ev[i + 1]));
+    float ms = 0;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+    int k = h->ev_kind[i / 2];
+    acc[k] += (double)ms * 1000.0;
+    cnt[k]++;
+  }
+  if (step_us) *step_us = cnt[0] ? acc[0] / cnt[0] : 0.0;
+  if (reset_us) *reset_us = cnt[1] ? acc[1] / cnt[1] : 0.0;
+  if (launches) *launches = cnt[0];
+  h->ev_used = 0;
+  return URGYM_OK;
+}
+
+const char* urgym_last_error(void* handle) {
+  Handle* h = (Handle*)handle;
+  return h ? h->err : g_err;
+}
+
+}  // extern "C"

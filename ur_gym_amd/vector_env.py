@@ -1,0 +1,248 @@
+"""Vectorised UR5e reach environments on one MI355X: the Gymnasium-VectorEnv-shaped surface of the HIP path.
+
+Mirrors, batched over ``num_envs`` environments, the Env API of the reference's ``RobotTaskEnv``
+(UR_gym/envs/core.py:222-320) as ``train.py:39-60`` / ``demo.py:6-17`` / ``model_test.py:27-49`` consume it:
+
+    reset(seed=None, options=None) -> (obs_dict, info)                      core.py:263-273
+    step(actions[N,6]) -> (obs_dict, reward[N], terminated[N], truncated[N], info)   core.py:303-317 + TimeLimit(100)
+
+Host Python only holds the per-env state as PyTorch-ROCm tensors and launches the fused HIP kernels through the
+C-ABI (include/urgym.h); every number is computed on the GPU.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _abi, _native
+
+try:  # gymnasium is optional (it is not installed in the build image)
+    from gymnasium import spaces as _spaces
+
+    Box, DictSpace = _spaces.Box, _spaces.Dict
+except Exception:  # pragma: no cover - exercised when gymnasium is absent
+
+    class Box:
+        def __init__(self, low, high, shape, dtype=np.float32):
+            self.low = np.full(shape, low, dtype=dtype)
+            self.high = np.full(shape, high, dtype=dtype)
+            self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+
+        def sample(self):
+            return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+        def __repr__(self):
+            return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+    class DictSpace(dict):
+        @property
+        def spaces(self):
+            return self
+
+        def sample(self):
+            return {k: v.sample() for k, v in self.items()}
+
+
+_TORCH_DTYPE = {C.c_double: torch.float64, C.c_float: torch.float32, C.c_int32: torch.int32, C.c_uint8: torch.uint8}
+
+
+class UR5ReachVectorEnv:
+    """N independent UR5{Ori,Obs,Dyn}Reach-v1 environments stepped by one fused kernel launch.
+
+    Observations are returned as views of persistent device tensors (zero-copy); they are overwritten by the next
+    ``step``/``reset``.  Pass ``copy_obs=True`` to get fresh tensors instead.
+    """
+
+    metadata = {"render_modes": []}
+
+    def __init__(self, env_id="UR5DynReach-v1", num_envs=1, device="cuda:0", seed=0, auto_reset=True,
+                 check_collision=True, copy_obs=False, **config_overrides):
+        if env_id not in _abi.ENV_IDS:
+            raise ValueError(f"unknown env id {env_id!r}; available: {sorted(_abi.ENV_IDS)}")
+        self.lib = _native.lib()  # raises if the HIP extension is missing
+        self.device = torch.device(device)
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise _native.NativeError("UR5ReachVectorEnv needs a ROCm GPU (torch device 'cuda:N'); there is no CPU path")
+        self.env_id, self.env_kind = env_id, _abi.ENV_IDS[env_id]
+        self.num_envs = int(num_envs)
+        self.copy_obs = copy_obs
+        self.obs_dim, self.goal_dim = _abi.OBS_DIMS[self.env_kind]
+        self.cfg = _abi.Config()
+        _native.check(self.lib.urgym_config_default(self.env_kind, self.num_envs, C.byref(self.cfg)))
+        self.cfg.auto_reset = int(bool(auto_reset))
+        self.cfg.check_collision = int(bool(check_collision))
+        for k, v in config_overrides.items():
+            if not hasattr(self.cfg, k):
+                raise TypeError(f"unknown config field {k!r}")
+            setattr(self.cfg, k, v)
+        self._seed = int(seed)
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        _native.check(self.lib.urgym_create(C.byref(self.cfg), dev_index, C.byref(self._h)))
+        # all buffers are torch tensors owned here; the C side only borrows the pointers
+        self.buf = {}
+        cb = _abi.Buffers()
+        for name, ct, shape in _abi.BUFFER_FIELDS:
+            t = torch.zeros(shape(self.num_envs, self.obs_dim, self.goal_dim), dtype=_TORCH_DTYPE[ct], device=self.device)
+            self.buf[name] = t
+            setattr(cb, name, C.cast(t.data_ptr(), C.POINTER(ct)))
+        self._cbuf = cb
+        _native.check(self.lib.urgym_bind(self._h, C.byref(cb)), self._h)
+        # spaces (core.py:241-248, UR5.py:251)
+        self.single_observation_space = DictSpace(
+            observation=Box(-10.0, 10.0, (self.obs_dim,), np.float32),
+            achieved_goal=Box(-10.0, 10.0, (self.goal_dim,), np.float32),
+            desired_goal=Box(-10.0, 10.0, (self.goal_dim,), np.float32),
+        )
+        self.single_action_space = Box(-1.0, 1.0, (6,), np.float32)
+        self.observation_space = DictSpace(
+            observation=Box(-10.0, 10.0, (self.num_envs, self.obs_dim), np.float32),
+            achieved_goal=Box(-10.0, 10.0, (self.num_envs, self.goal_dim), np.float32),
+            desired_goal=Box(-10.0, 10.0, (self.num_envs, self.goal_dim), np.float32),
+        )
+        self.action_space = Box(-1.0, 1.0, (self.num_envs, 6), np.float32)
+        self._needs_reset = True
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _obs(self):
+        keys = ("observation", "achieved_goal", "desired_goal")
+        if self.copy_obs:
+            return {k: self.buf[k].clone() for k in keys}
+        return {k: self.buf[k] for k in keys}
+
+    def _mask_ptr(self, ids_or_mask):
+        if ids_or_mask is None:
+            return None, None
+        m = torch.as_tensor(ids_or_mask, device=self.device)
+        if m.dtype == torch.bool or (m.dtype == torch.uint8 and m.numel() == self.num_envs):
+            mask = m.to(torch.uint8).contiguous()
+        else:
+            mask = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+            mask[m.long()] = 1
+        return mask, C.c_void_p(mask.data_ptr())
+
+    # ------------------------------------------------------------------------------------------------ Env API
+    def reset(self, seed=None, options=None, mask=None):
+        """core.py:263-273 for every env (or the masked subset). ``seed`` re-keys the counter-based sampler."""
+        if seed is not None:
+            self._seed = int(seed)
+            s = C.c_uint64(self._seed)
+        elif self._needs_reset:
+            s = C.c_uint64(self._seed)
+        else:
+            s = C.c_uint64(_abi.KEEP_SEED)
+        keep, mp = self._mask_ptr(mask)
+        _native.check(self.lib.urgym_reset(self._h, mp, s, self._stream()), self._h)
+        self._needs_reset = False
+        info = {"is_success": self.buf["is_success"].bool()}
+        return self._obs(), info
+
+    def step(self, actions):
+        """core.py:303-317 + TimeLimit; finished envs are auto-reset (their terminal observation is in
+        info['final_observation'], valid where info['_final_observation'])."""
+        if self._needs_reset:
+            raise RuntimeError("call reset() before step()")
+        a = torch.as_tensor(actions, device=self.device)
+        if a.dtype != torch.float32 or not a.is_contiguous():
+            a = a.to(torch.float32).contiguous()
+        if a.shape != (self.num_envs, 6):
+            raise ValueError(f"actions must have shape ({self.num_envs}, 6), got {tuple(a.shape)}")
+        _native.check(self.lib.urgym_step(self._h, C.c_void_p(a.data_ptr()), self._stream()), self._h)
+        b = self.buf
+        terminated, truncated = b["terminated"].bool(), b["truncated"].bool()
+        info = {"is_success": b["is_success"].bool(), "collision": b["collision"].bool()}
+        if self.cfg.auto_reset:
+            info["_final_observation"] = terminated | truncated
+            info["final_observation"] = {"observation": b["final_observation"], "achieved_goal": b["final_achieved_goal"],
+                                         "desired_goal": b["final_desired_goal"]}
+        reward = b["reward"].clone() if self.copy_obs else b["reward"]
+        return self._obs(), reward, terminated, truncated, info
+
+    def rollout(self, actions):
+        """K fused steps without returning to Python in between; ``actions`` is [K, N, 6] float32 on the device."""
+        a = torch.as_tensor(actions, device=self.device, dtype=torch.float32).contiguous()
+        if a.dim() != 3 or a.shape[1:] != (self.num_envs, 6):
+            raise ValueError("actions must be [K, N, 6]")
+        _native.check(self.lib.urgym_rollout(self._h, C.c_void_p(a.data_ptr()), int(a.shape[0]), self._stream()), self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self.lib.urgym_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --------------------------------------------------------------------------------- task-level setters (a13)
+    def set_goal(self, ids, goal):
+        """ReachOri.set_goal (reach.py:202-204) for env ids; goal is [len(ids), 6] (xyz + rpy)."""
+        ids = torch.as_tensor(ids, device=self.device).long()
+        g = torch.as_tensor(goal, device=self.device, dtype=torch.float64).reshape(len(ids), -1)
+        self.buf["goal"][: g.shape[1], ids] = g.T
+        self._refresh(ids)
+
+    def set_goal_and_obstacle(self, ids, data):
+        """Reach{Obs,Dyn}.set_goal_and_obstacle (reach.py:328-335, 702-713).
+        Obs: data = [goal xyz, obstacle xyz+rpy] (9); Dyn: [goal 6, obstacle_start 6, obstacle_end 6] (18)."""
+        ids = torch.as_tensor(ids, device=self.device).long()
+        d = torch.as_tensor(data, device=self.device, dtype=torch.float64).reshape(len(ids), -1)
+        if self.env_kind == _abi.ENV_OBS:
+            assert d.shape[1] == 9
+            self.buf["goal"][:3, ids] = d[:, :3].T
+            self.buf["obst_start"][:, ids] = d[:, 3:9].T
+        elif self.env_kind == _abi.ENV_DYN:
+            assert d.shape[1] == 18
+            self.buf["goal"][:, ids] = d[:, :6].T
+            self.buf["obst_start"][:, ids] = d[:, 6:12].T
+            self.buf["obst_end"][:, ids] = d[:, 12:18].T
+        else:
+            raise TypeError("UR5OriReach-v1 has no obstacle; use set_goal")
+        self._refresh(ids)
+
+    def _refresh(self, ids=None):
+        keep, mp = self._mask_ptr(ids)
+        _native.check(self.lib.urgym_refresh(self._h, mp, self._stream()), self._h)
+
+    STATE_KEYS = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist", "step_count",
+                  "episode_id")
+
+    def get_state(self):
+        """Snapshot of the per-env state tensors (SoA layout of include/urgym.h), on the host."""
+        return {k: self.buf[k].detach().cpu().numpy().copy() for k in self.STATE_KEYS}
+
+    def set_state(self, state, refresh=False):
+        """Overwrite state tensors (teacher-forced parity tests). With refresh=True the observation, collision flag and
+        link distances are recomputed for all envs (obstacle placed at obst_start)."""
+        for k, v in state.items():
+            t = torch.as_tensor(np.asarray(v), device=self.device).reshape(self.buf[k].shape)
+            self.buf[k].copy_(t.to(self.buf[k].dtype))
+        if refresh:
+            self._refresh(None)
+        self._needs_reset = False
+
+    # ------------------------------------------------------------------------------------------------ timing
+    def enable_timing(self, on=True):
+        _native.check(self.lib.urgym_enable_timing(self._h, int(on)), self._h)
+
+    def query_timing(self):
+        """(avg step-kernel us, avg reset-kernel us, #step launches) since the last query — HIP events on the launch stream."""
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        _native.check(self.lib.urgym_query_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), self._h)
+        return a.value, b.value, n.value
+
+
+def make_vec(env_id, num_envs=1, **kwargs):
+    """Counterpart of ``gymnasium.make(id)`` for the ids the reference registers (UR_gym/__init__.py:19-42)."""
+    return UR5ReachVectorEnv(env_id, num_envs=num_envs, **kwargs)
