@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the fused UR5e reach step on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one call of VectorEnv.step() (fused step kernel + device-side auto-reset of finished envs) over one
+batch of synthetic actions for every environment of this rank.  Workload at N=1: BASELINE.json configs[3],
+UR5DynReach-v1 with 65536 environments on one MI355X (the configuration the metric is quoted on).  For N>1 the
+driver launches one rank per GPU through torch.distributed.run; environments shard across ranks with no
+data-path collective (weak scaling: 65536 envs per GPU); the barrier + max-over-ranks timing uses RCCL.
+
+Rank 0 prints ONE JSON line.  `roofline.achieved` prices the dominant kernel (env_kernel<Dyn, STEP>) with the
+algorithmic bytes of SURVEY.md §8(d) (418 B per env-step) against the HBM peak; the kernel's duration is measured
+live with HIP events on the launch stream (urgym_enable_timing).  `cpu_baseline` times the CPU oracle
+(oracle/, kind "port": the reference's PyBullet path cannot run here) on rank 0's host cores over a bounded
+sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418}
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(env_id, seed, budget_s=12.0):
+    """Oracle (CPU restatement) on all host cores of this process, same workload shape, bounded sample."""
+    from oracle import binding as ob
+    from ur_gym_amd import _abi
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    kind = _abi.ENV_IDS[env_id]
+    n = 2048
+    env = ob.OracleEnv(kind, n, threads=cores)
+    env.reset(seed=seed)
+    rng = np.random.default_rng(seed)
+    acts = rng.uniform(-1, 1, (8, n, 6)).astype(np.float32)
+    # calibrate on 2 steps, then run as many steps as fit in the budget (at least 4)
+    t0 = time.perf_counter()
+    for k in range(2):
+        env.step(acts[k])
+    per_step = (time.perf_counter() - t0) / 2
+    steps = int(max(4, min(200, budget_s / max(per_step, 1e-6))))
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step(acts[k % len(acts)])
+    dt = time.perf_counter() - t0
+    env.close()
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {steps} steps of {env_id}, random actions, auto-reset on ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--env", default="UR5DynReach-v1")
+    ap.add_argument("--num-envs", type=int, default=65536, help="environments PER GPU")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gather-obs", action="store_true", help="all-gather observations over RCCL every step (optional)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rollout", action="store_true", help="enqueue all K steps through urgym_rollout (no Python per step)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from ur_gym_amd import make_vec
+
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    n = args.num_envs
+    env = make_vec(args.env, num_envs=n, device=dev, seed=args.seed + 1000 * rank)
+    env.reset(seed=args.seed + 1000 * rank)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed + rank)
+    n_act = min(args.steps + args.warmup, 64)  # distinct action batches, cycled (random policy as demo.py:11)
+    actions = torch.rand((n_act, n, 6), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
+    gathered = None
+    if args.gather_obs and world > 1:
+        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device=dev)
+
+    def one_step(k):
+        env.step(actions[k % n_act])
+        if gathered is not None:
+            dist.all_gather_into_tensor(gathered, env.buf["observation"])
+
+    for k in range(args.warmup):
+        one_step(k)
+    torch.cuda.synchronize(dev)
+    env.enable_timing(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    if args.rollout and gathered is None:
+        env.rollout(torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)]))
+    else:
+        for k in range(args.steps):
+            one_step(args.warmup + k)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    step_us, reset_us, launches = env.query_timing()
+    env.enable_timing(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    status = env.buf["status"]
+    anomalies = int((status != 0).sum().item())
+    episodes = int(env.buf["episode_id"].sum().item())
+    if rank == 0:
+        total_envs = n * world
+        value = total_envs * args.steps / elapsed
+        algo = ALGO_BYTES[args.env] * n  # bytes one launch of the step kernel has to move, per rank
+        achieved = algo / (step_us * 1e-6) / 1e9 if step_us > 0 else 0.0
+        out = {
+            "metric": "env-steps/sec (whole node)",
+            "value": value,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.env} N={n} per GPU, random actions U(-1,1), auto-reset, seed {args.seed}",
+                       "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "env_kernel<Dyn,STEP>" if args.env == "UR5DynReach-v1" else "env_kernel<STEP>",
+                         "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
+                         "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
+                         "note": "the kernel is VALU/LDS-bound in the GJK distance queries, not HBM-bound (DESIGN.md)"},
+            "anomalous_envs": anomalies,
+            "episodes_started": episodes,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -254,10 +254,32 @@ Shape make_sphere(double radius, const X3& pose) {
   s.pose = pose;
   return s;
 }
+// What-if switch for precision studies of the HIP path (tests only): bit0 = hull vertices rounded to float32,
+// bit1 = support scan evaluated in float32 (direction cast, fmaf chain z,y,x as on the device).
+thread_local int g_emulate = 0;
+
 // [BULLET] btConvexShape::localGetSupportVertexWithoutMarginNonVirtual
 V3 support_local(const Shape& s, V3 d) {
   switch (s.type) {
     case SH_HULL: {
+      if (g_emulate) {
+        int bi = 0;
+        if (g_emulate & 2) {
+          float best = -3.0e38f, dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+          for (int i = 0; i < s.nverts; i++) {
+            float v = std::fmaf((float)s.verts[i][2], dz, std::fmaf((float)s.verts[i][1], dy, (float)s.verts[i][0] * dx));
+            if (v > best) { best = v; bi = i; }
+          }
+        } else {
+          double best = -1e300;
+          for (int i = 0; i < s.nverts; i++) {
+            double v = (double)(float)s.verts[i][0] * d.x + (double)(float)s.verts[i][1] * d.y + (double)(float)s.verts[i][2] * d.z;
+            if (v > best) { best = v; bi = i; }
+          }
+        }
+        if (g_emulate & 1) return v3((double)(float)s.verts[bi][0], (double)(float)s.verts[bi][1], (double)(float)s.verts[bi][2]);
+        return v3(s.verts[bi][0], s.verts[bi][1], s.verts[bi][2]);
+      }
       double best = -1e300;
       int bi = 0;
       for (int i = 0; i < s.nverts; i++) {
@@ -1149,6 +1171,7 @@ int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacl
   *collision = check_collision(link, has_obstacle != 0, has_obstacle ? &obst : nullptr, margin) ? 1 : 0;
   return status;
 }
+void urgym_oracle_set_emulation(int flags) { g_emulate = flags; }
 void urgym_oracle_philox(uint64_t seed, uint32_t env, uint32_t episode, uint32_t attempt, double* u20) {
   Draws d = draw_attempt(seed, env, episode, attempt);
   std::memcpy(u20, d.u, sizeof(d.u));

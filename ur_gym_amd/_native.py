@@ -30,6 +30,11 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  Import torch
+    # FIRST so that this extension binds to the very runtime instance whose streams and device pointers it is handed;
+    # loading the extension first would pull in a second, system-wide runtime.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise NativeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

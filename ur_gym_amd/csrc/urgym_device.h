@@ -3,7 +3,8 @@
 // Numeric plan: everything that the reference evaluates in float64 and that feeds an
 // output with a large weight (FK chain, Euler/quaternion conversions, pose distances, the GJK simplex) is done in
 // float64 here as well; only the O(#vertices) support scan over a convex hull runs in float32 on LDS-resident
-// vertices (it only has to pick the right vertex — the vertex is then re-read and transformed in float64).
+// vertices (it only has to pick the right vertex — the vertex is then re-read from the float64 table in global
+// memory (L2-resident, one 24-byte read per support call) and transformed in float64).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -156,6 +157,8 @@ struct ShapeDesc {
   int type;
   int blk_off;  // hull: first 4-vertex block in the LDS table
   int nblk;     // hull: number of 4-vertex blocks
+  int vert_off; // hull: first vertex in the float64 vertex table (global memory)
+  int nverts;   // hull: number of vertices
   double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
   D3 center;    // a point inside (initial direction only)
 };
@@ -166,7 +169,8 @@ struct ShapeDesc {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const v4f* lds_f4_ptr;  // explicit LDS pointer: ds_read_b128, never flat
 
-__device__ __forceinline__ D3 hull_support(lds_f4_ptr tab, int blk_off, int nblk, float dx, float dy, float dz) {
+// Returns the index (within the hull) of the supporting vertex; the caller re-reads that vertex in float64.
+__device__ __forceinline__ int hull_support(lds_f4_ptr tab, int blk_off, int nblk, float dx, float dy, float dz) {
   lds_f4_ptr t4 = tab + blk_off * 3;
   float best = -3.0e38f;
   int bb = 0;
@@ -185,16 +189,19 @@ __device__ __forceinline__ D3 hull_support(lds_f4_ptr tab, int blk_off, int nblk
   float t0 = fmaf(Z.x, dz, fmaf(Y.x, dy, X.x * dx));
   float t1 = fmaf(Z.y, dz, fmaf(Y.y, dy, X.y * dx));
   float t2 = fmaf(Z.z, dz, fmaf(Y.z, dy, X.z * dx));
-  D3 r = d3(X.w, Y.w, Z.w);
-  if (t2 >= best) r = d3(X.z, Y.z, Z.z);
-  if (t1 >= best) r = d3(X.y, Y.y, Z.y);
-  if (t0 >= best) r = d3(X.x, Y.x, Z.x);
-  return r;
+  int j = 3;
+  if (t2 >= best) j = 2;
+  if (t1 >= best) j = 1;
+  if (t0 >= best) j = 0;
+  return bb * 4 + j;
 }
 
-__device__ __forceinline__ D3 support_local(lds_f4_ptr tab, const ShapeDesc& s, D3 d) {
+__device__ __forceinline__ D3 support_local(lds_f4_ptr tab, const double* __restrict__ verts64, const ShapeDesc& s, D3 d) {
   if (s.type == SH_HULL) {
-    return hull_support(tab, s.blk_off, s.nblk, (float)d.x, (float)d.y, (float)d.z);
+    int i = hull_support(tab, s.blk_off, s.nblk, (float)d.x, (float)d.y, (float)d.z);
+    i = min(i, s.nverts - 1);  // the last LDS block is padded with copies of the last vertex
+    const double* p = verts64 + (size_t)(s.vert_off + i) * 3;
+    return d3(p[0], p[1], p[2]);
   } else if (s.type == SH_CYLZ) {
     double sn = sqrt(d.x * d.x + d.y * d.y);
     double hz = d.z < 0.0 ? -s.hz : s.hz;
@@ -234,56 +241,75 @@ __device__ __forceinline__ D3 tri_closest(D3 a, D3 b, D3 c, int& mask) {
 
 enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4 };
 
-// Distance between the CORE shapes A (posed by T = pose of A in B's frame) and B (canonical frame).
-// stop_above: as soon as a separating direction proves core distance > stop_above the search stops and the lower
-// bound is returned with GJK_SEPARATED (boolean "closer than margin?" queries); pass a huge value for exact distance.
-__device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const ShapeDesc& A, const X3& T, const ShapeDesc& B,
-                                                 double stop_above, int& info) {
-  const double TOL = 1.0e-10;     // relative gap on the squared distance (Bullet double build: 1e-12)
-  const double TINY2 = 1.0e-20;   // |v|^2 below this = cores touching/overlapping
+// Closest distance between the CORE shapes A (posed by T = pose of A in B's frame) and B (canonical frame):
+// the same algorithm the reference reaches through p.getClosestPoints (pyb_setup.py:401-452), i.e. Bullet's
+// btGjkPairDetector + btVoronoiSimplexSolver in the double-precision build — same start axis (world +Y, handed in
+// as v0 in B's frame), same vertex-reduction order, same termination tests (relative 1e-12 on the squared distance,
+// duplicate-vertex, no-progress, sliver tetrahedron) — so that the iterates, and with them the last bits of the
+// distance, follow the oracle's.  Everything except the hull support scan is float64.
+//   max_d : Bullet's early-out distance (marginA + marginB + 0.02 + query threshold) on the core distance; when a
+//           separating axis proves the cores farther apart than that the search stops (GJK_SEPARATED).
+// Returns the core distance |v|; GJK_PENETRATING when the cores touch/overlap (Bullet would enter EPA).
+__device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const double* __restrict__ verts64, const ShapeDesc& A,
+                                                    const X3& T, const ShapeDesc& B, D3 v0, double max_d, int& info) {
+  const double REL_ERROR2 = 1.0e-12;
+  const double EPS = 2.220446049250313e-16;
   info = 0;
-  D3 v = apply(T, A.center) - B.center;
-  if (len2(v) < 1.0e-12) v = d3(0.0, 1.0, 0.0);
-  double sq = len2(v);
+  D3 v = v0;
+  double sq = 1.0e300;
+  const double max_d2 = max_d * max_d;
   D3 s0 = d3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
+  D3 last_w = d3(1e300, 1e300, 1e300);
   int n = 0;
-  for (int it = 0; it < 64; it++) {
-    D3 p = apply(T, support_local(tab, A, rotT(T, -v)));
-    D3 q = support_local(tab, B, v);
+  bool check_simplex = false;
+  int degenerate = 0;
+  int iter = 0;
+  for (;;) {
+    D3 p = apply(T, support_local(tab, verts64, A, rotT(T, -v)));
+    D3 q = support_local(tab, verts64, B, v);
     D3 w = p - q;
     double delta = dot(v, w);
-    if (delta > 0.0 && delta * delta > sq * stop_above * stop_above) {
-      info |= GJK_SEPARATED;
-      return delta / sqrt(sq);
+    if (delta > 0.0 && delta * delta > sq * max_d2) { degenerate = 10; check_simplex = true; break; }
+    {
+      bool in = (n > 0 && len2(s0 - w) <= 1e-12) || (n > 1 && len2(s1 - w) <= 1e-12) || (n > 2 && len2(s2 - w) <= 1e-12) ||
+                (n > 3 && len2(s3 - w) <= 1e-12) || (w.x == last_w.x && w.y == last_w.y && w.z == last_w.z);
+      if (in) { degenerate = 1; check_simplex = true; break; }
     }
-    if (n > 0) {
-      // new support point already in the simplex, or no measurable gap left: v is the closest point
-      bool dup = (len2(w - s0) <= 1e-24) || (n > 1 && len2(w - s1) <= 1e-24) || (n > 2 && len2(w - s2) <= 1e-24);
-      if (dup || (sq - delta) <= sq * TOL) return sqrt(sq);
-    }
-    // add w
+    double f0 = sq - delta, f1 = sq * REL_ERROR2;
+    if (f0 <= f1) { degenerate = (f0 <= 0.0) ? 2 : 11; check_simplex = true; break; }
+    last_w = w;
     if (n == 0) s0 = w; else if (n == 1) s1 = w; else if (n == 2) s2 = w; else s3 = w;
     n++;
-    D3 nv;
-    int mask;
+    // ---- closest point of the simplex to the origin + vertex reduction
+    D3 nv = d3(0, 0, 0);
+    bool valid = true;
+    bool ua = true, ub = true, uc = true, ud = true;
+    bool reduce = true;
     if (n == 1) {
       nv = s0;
-      mask = 1;
+      reduce = false;
     } else if (n == 2) {
       D3 e = s1 - s0;
       double t = -dot(e, s0);
-      double ee = dot(e, e);
-      if (t <= 0.0) { nv = s0; mask = 1; }
-      else if (t >= ee) { nv = s1; mask = 2; }
-      else { nv = s0 + e * (t / ee); mask = 3; }
+      if (t > 0.0) {
+        double ee = dot(e, e);
+        if (t < ee) t /= ee;
+        else { t = 1.0; ua = false; }
+      } else {
+        t = 0.0;
+        ub = false;
+      }
+      nv = s0 + e * t;
+      uc = ud = false;
     } else if (n == 3) {
-      nv = tri_closest(s0, s1, s2, mask);
+      int m;
+      nv = tri_closest(s0, s1, s2, m);
+      ua = m & 1; ub = m & 2; uc = m & 4; ud = false;
     } else {
-      // tetrahedron: test the four faces; face f = (a,b,c) with opposite vertex o
+      // faces in Bullet's order: ABC|D, ACD|B, ADB|C, BDC|A
       double best = 1.0e300;
-      nv = d3(0, 0, 0);
-      mask = 15;
       bool any_out = false, degen = false;
+      ua = ub = uc = ud = false;
 #pragma unroll 1
       for (int f = 0; f < 4; f++) {
         D3 a = (f == 3) ? s1 : s0;
@@ -292,59 +318,55 @@ __device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const ShapeD
         D3 o = (f == 0) ? s3 : ((f == 1) ? s1 : ((f == 2) ? s2 : s0));
         D3 nrm = cross(b - a, c - a);
         double signp = -dot(a, nrm), signd = dot(o - a, nrm);
-        if (signd * signd < 1.0e-16) degen = true;
-        if (signp * signd < 0.0) {
-          any_out = true;
+        if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
+        else if (signp * signd < 0.0) {
           int m3;
           D3 pt = tri_closest(a, b, c, m3);
           double l = len2(pt);
-          if (l < best) {
+          if (!any_out || l < best) {
             best = l;
             nv = pt;
-            // map (a,b,c) bits back to (s0,s1,s2,s3)
-            int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
-            mask = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+            const bool ma = m3 & 1, mb = m3 & 2, mc = m3 & 4;
+            ua = (f == 3) ? false : ma;
+            ub = (f == 0) ? mb : ((f == 2) ? mc : ((f == 3) ? ma : false));
+            uc = (f == 0) ? mc : ((f == 1) ? mb : ((f == 3) ? mc : false));
+            ud = (f == 0) ? false : ((f == 1) ? mc : mb);
           }
+          any_out = true;
         }
       }
-      if (degen) return sqrt(sq);  // sliver tetrahedron: keep the last good closest point (Bullet: degenerate simplex 3)
-      if (!any_out) {
-        info |= GJK_PENETRATING;
-        return 0.0;
+      if (degen) {
+        valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
+        reduce = false;
+      } else if (!any_out) {
+        nv = d3(0, 0, 0);  // origin inside the tetrahedron
+        reduce = false;
       }
     }
-    // keep only the vertices that support the closest point, in order
-    {
-      D3 t0 = s0, t1 = s1, t2 = s2, t3 = s3;
-      int k = 0;
-      D3 o0 = t0, o1 = t1, o2 = t2;
-      // first used
-      int i0 = (mask & 1) ? 0 : ((mask & 2) ? 1 : ((mask & 4) ? 2 : 3));
-      int rest = mask & ~(1 << i0);
-      int i1 = (rest & 1) ? 0 : ((rest & 2) ? 1 : ((rest & 4) ? 2 : 3));
-      int rest2 = rest & ~(1 << i1);
-      int i2 = (rest2 & 1) ? 0 : ((rest2 & 2) ? 1 : ((rest2 & 4) ? 2 : 3));
-      o0 = (i0 == 0) ? t0 : ((i0 == 1) ? t1 : ((i0 == 2) ? t2 : t3));
-      o1 = (i1 == 0) ? t0 : ((i1 == 1) ? t1 : ((i1 == 2) ? t2 : t3));
-      o2 = (i2 == 0) ? t0 : ((i2 == 1) ? t1 : ((i2 == 2) ? t2 : t3));
-      k = __popc(mask);
-      s0 = o0; s1 = o1; s2 = o2;
-      n = k;
+    if (reduce) {
+      // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
+      if (n >= 4 && !ud) { n--; }
+      if (n >= 3 && !uc) { n--; D3 l = (n == 2) ? s2 : s3; s2 = l; }
+      if (n >= 2 && !ub) { n--; D3 l = (n == 1) ? s1 : ((n == 2) ? s2 : s3); s1 = l; }
+      if (n >= 1 && !ua) { n--; D3 l = (n == 0) ? s0 : ((n == 1) ? s1 : ((n == 2) ? s2 : s3)); s0 = l; }
     }
+    if (!valid) { degenerate = 3; check_simplex = true; break; }
     double nsq = len2(nv);
-    if (nsq < TINY2) {
-      info |= GJK_PENETRATING;
-      return 0.0;
-    }
-    if (sq - nsq <= 1.0e-15 * sq && it > 0) {
-      // no progress any more (float32 scan picked a near-tied vertex): converged to working precision
-      return sqrt(fmin(sq, nsq));
-    }
-    v = nv;
+    if (nsq < REL_ERROR2) { v = nv; degenerate = 6; check_simplex = true; break; }
+    double prev = sq;
     sq = nsq;
+    if (prev - sq <= EPS * prev) { degenerate = 12; check_simplex = true; break; }
+    v = nv;
+    if (iter++ > 1000) { info |= GJK_ITERCAP; break; }
+    if (n == 4) { degenerate = 13; break; }
   }
-  info |= GJK_ITERCAP;
-  return sqrt(sq);
+  double l2 = len2(v);
+  if (!check_simplex || l2 < REL_ERROR2) {
+    if (!(info & GJK_ITERCAP)) info |= GJK_PENETRATING;
+    return 0.0;
+  }
+  if (degenerate == 10) info |= GJK_SEPARATED;
+  return sqrt(l2);
 }
 
 }  // namespace urgym

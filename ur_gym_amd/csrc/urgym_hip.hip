@@ -55,6 +55,7 @@ struct DevTables {
   double joint_xyz[6][3];
   double capsule[6][7];
   int hull_blk_off[7];
+  int hull_vert_off[7];
 };
 __constant__ DevTables c_tab;
 
@@ -62,6 +63,7 @@ struct KParams {
   urgym_config cfg;
   urgym_buffers buf;
   const float* hull_table;  // packed 4-vertex blocks, MAX_HULL_BLOCKS * 12 floats
+  const double* hull_verts64;  // [UR5E_NUM_HULL_VERTS][3] exact link-frame vertices
   int hull_blocks;
   int obs_dim, goal_dim;
   uint32_t seed_lo, seed_hi;
@@ -76,6 +78,8 @@ __device__ __forceinline__ ShapeDesc hull_desc(int link /*1..6*/) {
   s.type = SH_HULL;
   s.blk_off = c_tab.hull_blk_off[link - 1];
   s.nblk = c_tab.hull_blk_off[link] - c_tab.hull_blk_off[link - 1];
+  s.vert_off = c_tab.hull_vert_off[link - 1];
+  s.nverts = c_tab.hull_vert_off[link] - c_tab.hull_vert_off[link - 1];
   s.hx = s.hy = s.hz = 0.0;
   const double* c = c_tab.capsule[link - 1];
   s.center = d3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]));
@@ -83,21 +87,21 @@ __device__ __forceinline__ ShapeDesc hull_desc(int link /*1..6*/) {
 }
 __device__ __forceinline__ ShapeDesc cyl_desc() {
   ShapeDesc s;
-  s.type = SH_CYLZ; s.blk_off = 0; s.nblk = 0;
+  s.type = SH_CYLZ; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0;
   s.hx = s.hy = CYL_R - M_CYL; s.hz = 0.5 * CYL_H - M_CYL;
   s.center = d3(0, 0, 0);
   return s;
 }
 __device__ __forceinline__ ShapeDesc box_desc(double hx, double hy, double hz, double margin) {
   ShapeDesc s;
-  s.type = SH_BOX; s.blk_off = 0; s.nblk = 0;
+  s.type = SH_BOX; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0;
   s.hx = hx - margin; s.hy = hy - margin; s.hz = hz - margin;
   s.center = d3(0, 0, 0);
   return s;
 }
 __device__ __forceinline__ ShapeDesc point_desc() {
   ShapeDesc s;
-  s.type = SH_POINT; s.blk_off = 0; s.nblk = 0; s.hx = s.hy = s.hz = 0.0;
+  s.type = SH_POINT; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0; s.hx = s.hy = s.hz = 0.0;
   s.center = d3(0, 0, 0);
   return s;
 }
@@ -262,7 +266,8 @@ __device__ void sample_episode(const KParams& P, lds_f4_ptr tab, int n, int& fla
     if (!fail) {
       Tt.t = d3(goal[0], goal[1], goal[2]);
       int info;
-      double core = gjk_core_distance(tab, ta, rel(To, Tt), cyl_desc(), 1e30, info);
+      // Bullet's pair detector starts from the world +Y axis; B's frame is the obstacle's
+      double core = gjk_core_distance(tab, P.hull_verts64, ta, rel(To, Tt), cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
       double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
       fail = dist < cfg.target_clearance;
     }
@@ -341,6 +346,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
 
   // ---- P1: state, joint update, obstacle motion, FK to link L, culling, pose of hull L in the obstacle frame
   X3 Trel = identity_x3();
+  D3 v0_obst = d3(0, 1, 0);  // world +Y (Bullet's initial separating axis) seen from the obstacle frame
   if (active) {
     double q[6];
     for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
@@ -419,6 +425,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       quat_to_rot(oq, To.r);
       To.t = d3(opos[0], opos[1], opos[2]);
       Trel = rel(To, TL);
+      v0_obst = rotT(To, d3(0, 1, 0));
     }
   }
   __syncthreads();
@@ -436,7 +443,8 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       bool have;
       ShapeDesc sa, sb;
       X3 Tab;
-      double msum, stop;
+      double msum, max_d;
+      D3 v0;
       int e = lane;
       const bool obst_round = HAS_OBST && round == 0;
       if (obst_round) {
@@ -445,7 +453,8 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
         sb = cyl_desc();
         Tab = Trel;
         msum = M_HULL + M_CYL;
-        stop = 1e30;
+        max_d = msum + 0.02 + 5.0;  // get_link_distances queries with distance=5.0 (pyb_setup.py:452)
+        v0 = v0_obst;
       } else {
         const int it = (round - first_q) * THREADS + tid;
         have = it < qn;
@@ -464,6 +473,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
           sb = hull_desc(lb < 1 ? 1 : lb);
           Tab = rel(T, TA);
           msum = M_HULL + M_HULL;
+          v0 = rotT(T, d3(0, 1, 0));
         } else {
           const bool tbl = (kind == Q_TABLE);
           sa = hull_desc(lb < 1 ? 1 : lb);
@@ -471,12 +481,13 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
           Tab = T;
           Tab.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
           msum = M_HULL + (tbl ? M_TABLE : M_TRACK);
+          v0 = d3(0, 1, 0);
         }
-        stop = cfg.collision_margin + msum;
+        max_d = msum + 0.02 + cfg.collision_margin;  // check_collision queries with distance=0.01 (pyb_setup.py:402-422)
       }
       if (have) {
         int info;
-        const double core = gjk_core_distance(tab, sa, Tab, sb, stop, info);
+        const double core = gjk_core_distance(tab, P.hull_verts64, sa, Tab, sb, v0, max_d, info);
         if (obst_round) {
           double dist = core - msum;
           if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[lane], URGYM_STATUS_PENETRATION); }
@@ -605,6 +616,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
         }
       }
       if (reward != reward) flags |= URGYM_STATUS_NAN;
+      if (!update_ld) flags &= ~(URGYM_STATUS_PENETRATION | URGYM_STATUS_GJK_ITER);  // the distances were not consumed (reach.py:766-770)
       int sc = step_count + 1;
       bool truncated = sc >= cfg.max_episode_steps;  // TimeLimit (UR_gym/__init__.py:41)
       for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = q[i];
@@ -702,6 +714,7 @@ struct Handle {
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
   float* d_hull = nullptr;
+  double* d_verts64 = nullptr;
   int hull_blocks = 0;
   uint64_t seed = 0;
   int pp = 0;
@@ -775,6 +788,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.cfg = h->cfg;
   P.buf = h->buf;
   P.hull_table = h->d_hull;
+  P.hull_verts64 = h->d_verts64;
   P.hull_blocks = h->hull_blocks;
   P.obs_dim = h->obs_dim;
   P.goal_dim = h->goal_dim;
@@ -895,6 +909,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   int blk = 0;
   for (int hidx = 0; hidx < 6; hidx++) {
     t.hull_blk_off[hidx] = blk;
+    t.hull_vert_off[hidx] = UR5E_HULL_OFFSET[hidx];
     int v0 = UR5E_HULL_OFFSET[hidx], v1 = UR5E_HULL_OFFSET[hidx + 1];
     for (int v = v0; v < v1; v += 4, blk++) {
       for (int j = 0; j < 4; j++) {
@@ -906,6 +921,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     }
   }
   t.hull_blk_off[6] = blk;
+  t.hull_vert_off[6] = UR5E_HULL_OFFSET[6];
   h->hull_blocks = blk;
   if (blk > MAX_HULL_BLOCKS) { delete h; return fail(nullptr, URGYM_ERR_STATE, "hull table larger than the LDS budget"); }
   e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
@@ -914,6 +930,9 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMalloc(hull table)", e); }
   e = hipMemcpy(h->d_hull, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) { hipFree(h->d_hull); delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpy(hull table)", e); }
+  e = hipMalloc(&h->d_verts64, sizeof(UR5E_HULL_VERTS));
+  if (e == hipSuccess) e = hipMemcpy(h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(h->d_hull); if (h->d_verts64) hipFree(h->d_verts64); delete h; return fail(nullptr, URGYM_ERR_HIP, "hull vertex table upload", e); }
   *handle = h;
   return URGYM_OK;
 }
@@ -924,6 +943,7 @@ int urgym_destroy(void* handle) {
   hipSetDevice(h->device);
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_hull) hipFree(h->d_hull);
+  if (h->d_verts64) hipFree(h->d_verts64);
   delete h;
   return URGYM_OK;
 }
