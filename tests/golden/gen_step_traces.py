@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/step_trace_{ori,obs,dyn}.npz with the CPU oracle (seeded), as regression vectors for the
+HIP path.  These are outputs of the build's own oracle, not of the reference (which cannot run here: no pybullet):
+
+    python tests/golden/gen_step_traces.py
+
+Each file: the post-reset state, K action batches, and per step observation / reward / flags, plus the final state.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import binding as ob  # noqa: E402
+from ur_gym_amd import _abi  # noqa: E402
+
+N, K, SEED = 48, 36, 20241004
+STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist", "step_count", "episode_id")
+
+
+def main():
+    for name, kind in (("ori", _abi.ENV_ORI), ("obs", _abi.ENV_OBS), ("dyn", _abi.ENV_DYN)):
+        env = ob.OracleEnv(kind, N, threads=4)
+        env.reset(seed=SEED)
+        rng = np.random.default_rng(SEED + kind)
+        out = {"seed": SEED, "kind": kind}
+        for k in STATE:
+            out["reset_" + k] = env.buf[k].copy()
+        out["reset_observation"] = env.buf["observation"].copy()
+        acts = (rng.uniform(-1, 1, (K, N, 6)) * rng.choice([0.3, 1.0, 1.7], (K, N, 1))).astype(np.float32)  # some beyond +-1: clipped
+        rec = {k: [] for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success",
+                               "collision", "final_observation", "link_dist", "q")}
+        for t in range(K):
+            env.step(acts[t])
+            for k in rec:
+                rec[k].append(env.buf[k].copy())
+        out["actions"] = acts
+        for k, v in rec.items():
+            out["step_" + k] = np.stack(v)
+        for k in STATE:
+            out["final_" + k] = env.buf[k].copy()
+        out["final_status"] = env.buf["status"].copy()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), f"step_trace_{name}.npz")
+        np.savez_compressed(path, **out)
+        done = out["step_terminated"].sum() + out["step_truncated"].sum()
+        print(name, "episodes finished in trace:", int(done), "size", os.path.getsize(path))
+        env.close()
+
+
+if __name__ == "__main__":
+    main()

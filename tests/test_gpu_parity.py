@@ -1,0 +1,300 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI (ur_gym_amd.vector_env -> ctypes ->
+liburgym_hip.so), against the CPU oracle on the same seeded inputs, against the committed golden traces, and — at
+BASELINE.json's full size — through size-independent properties.
+
+Tolerances (written here, north_star: "within 1e-4 abs"):
+  observation / achieved / desired   1e-4 abs  (measured: ~1e-6; Euler angles compared modulo 2*pi: atan2 branch cut)
+  link distances (state)             2e-6 abs  (float32 support scan: a near-tied vertex can change Bullet's early-exit
+                                               path, ~1 query in 1e4; DESIGN.md "Precision")
+  reward                             1e-4 abs for Ori / Dyn; 3e-4 abs for Obs, whose 100x weight on the link-distance
+                                               change (reach.py:371) amplifies that 2e-6
+  flags (terminated/truncated/is_success/collision), step counters: exact
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ur_gym_amd import _abi
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KINDS = [("UR5OriReach-v1", _abi.ENV_ORI), ("UR5ObsReach-v1", _abi.ENV_OBS), ("UR5DynReach-v1", _abi.ENV_DYN)]
+EULER_COLS = {_abi.ENV_ORI: [3, 4, 5], _abi.ENV_OBS: [3, 4, 5], _abi.ENV_DYN: [3, 4, 5, 21, 22, 23]}
+REWARD_TOL = {_abi.ENV_ORI: 1e-4, _abi.ENV_OBS: 3e-4, _abi.ENV_DYN: 1e-4}
+OBS_TOL, LD_TOL = 1e-4, 2e-6
+STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist", "step_count", "episode_id")
+
+
+def make_vec(*a, **k):
+    from ur_gym_amd import make_vec as mk
+
+    return mk(*a, device="cuda:0", **k)
+
+
+def np_(t):
+    return t.detach().cpu().numpy()
+
+
+def obs_diff(kind, a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    cols = [c for c in EULER_COLS[kind] if c < d.shape[-1]]
+    d[..., cols] = np.minimum(d[..., cols], np.abs(d[..., cols] - 2 * np.pi))
+    return float(d.max()) if d.size else 0.0
+
+
+def assert_outputs_match(kind, env, ref, where=""):
+    """ref: dict of numpy arrays (oracle buffers or a golden record)."""
+    assert obs_diff(kind, np_(env.buf["observation"]), ref["observation"]) < OBS_TOL, where
+    assert obs_diff(kind, np_(env.buf["achieved_goal"]), ref["achieved_goal"]) < OBS_TOL, where
+    assert np.abs(np_(env.buf["desired_goal"]) - ref["desired_goal"]).max() < 1e-6, where
+    assert np.abs(np_(env.buf["reward"]) - ref["reward"]).max() < REWARD_TOL[kind], where
+    for k in ("terminated", "truncated", "is_success", "collision"):
+        assert np.array_equal(np_(env.buf[k]), ref[k]), (where, k)
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_reset_parity(oracle, env_id, kind):
+    n = 500  # ragged: not a multiple of the 64-env group
+    env = make_vec(env_id, num_envs=n, seed=17)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    env.reset(seed=17)
+    orc.reset(seed=17)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    for k in ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_vel"):
+        assert np.abs(st[k] - orc.buf[k]).max() < 1e-12, k  # same Philox stream, same float64 formulas
+    assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12
+    assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
+    assert np.array_equal(st["step_count"], orc.buf["step_count"]) and np.array_equal(st["episode_id"], orc.buf["episode_id"])
+    assert obs_diff(kind, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    # masked reset: only the selected envs start a new episode
+    mask = np.zeros(n, bool)
+    mask[[0, 63, 64, 499]] = True
+    before = np_(env.buf["observation"]).copy()
+    env.reset(mask=torch.from_numpy(mask))
+    orc.reset(mask=mask)
+    torch.cuda.synchronize()
+    assert np.array_equal(np_(env.buf["observation"])[~mask], before[~mask])
+    assert np.array_equal(np_(env.buf["episode_id"]), orc.buf["episode_id"])
+    assert obs_diff(kind, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,kind", KINDS)
+def test_step_parity_against_oracle(oracle, env_id, kind):
+    """Both sides free-run from the same seed with the same actions (auto-reset on): every output of every step."""
+    n, steps = 320, 70
+    env = make_vec(env_id, num_envs=n, seed=23)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    env.reset(seed=23)
+    orc.reset(seed=23)
+    rng = np.random.default_rng(23)
+    finished = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        orc.step(a)
+        torch.cuda.synchronize()
+        assert_outputs_match(kind, env, orc.buf, where=f"step {t}")
+        done = (orc.buf["terminated"] | orc.buf["truncated"]).astype(bool)
+        finished += int(done.sum())
+        if done.any():
+            assert obs_diff(kind, np_(env.buf["final_observation"])[done], orc.buf["final_observation"][done]) < OBS_TOL
+        st = env.get_state()
+        assert np.abs(st["q"] - orc.buf["q"]).max() < 1e-12
+        assert np.array_equal(st["step_count"], orc.buf["step_count"]) and np.array_equal(st["episode_id"], orc.buf["episode_id"])
+        if kind != _abi.ENV_ORI:
+            assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
+            assert np.abs(st["obst_pos"] - orc.buf["obst_pos"]).max() < 1e-12
+            assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12
+    assert finished > 20  # collisions / truncations did happen, so the auto-reset path was exercised
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+@pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2]])
+def test_golden_traces(name, env_id, kind):
+    g = np.load(os.path.join(HERE, "golden", f"step_trace_{name}.npz"))
+    n = g["actions"].shape[1]
+    env = make_vec(env_id, num_envs=n, seed=int(g["seed"]))
+    env.reset(seed=int(g["seed"]))
+    torch.cuda.synchronize()
+    st = env.get_state()
+    for k in STATE:
+        tol = LD_TOL if k == "link_dist" else 1e-12
+        assert np.abs(st[k].astype(np.float64) - g["reset_" + k]).max() <= tol, k
+    assert obs_diff(kind, np_(env.buf["observation"]), g["reset_observation"]) < OBS_TOL
+    for t in range(g["actions"].shape[0]):
+        env.step(torch.from_numpy(g["actions"][t]).cuda())
+        torch.cuda.synchronize()
+        ref = {k: g["step_" + k][t] for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated",
+                                               "truncated", "is_success", "collision")}
+        assert_outputs_match(kind, env, ref, where=f"golden step {t}")
+    st = env.get_state()
+    for k in STATE:
+        tol = LD_TOL if k == "link_dist" else 1e-12
+        assert np.abs(st[k].astype(np.float64) - g["final_" + k]).max() <= tol, k
+    env.close()
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129])
+def test_ragged_sizes(oracle, n):
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=n)
+    orc = oracle.OracleEnv(_abi.ENV_DYN, n, threads=2)
+    env.reset(seed=n)
+    orc.reset(seed=n)
+    rng = np.random.default_rng(n)
+    for t in range(12):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        orc.step(a)
+        torch.cuda.synchronize()
+        assert_outputs_match(_abi.ENV_DYN, env, orc.buf, where=f"n={n} step {t}")
+    env.close()
+
+
+def test_action_clipping_and_nan_guard(oracle):
+    n = 64
+    env = make_vec("UR5OriReach-v1", num_envs=n, seed=1)
+    orc = oracle.OracleEnv(_abi.ENV_ORI, n)
+    env.reset(seed=1)
+    orc.reset(seed=1)
+    a = np.random.default_rng(0).uniform(-5, 5, (n, 6)).astype(np.float32)  # far outside [-1,1]: clipped (UR5.py:275)
+    env.step(torch.from_numpy(a).cuda())
+    orc.step(np.clip(a, -1, 1))
+    torch.cuda.synchronize()
+    assert_outputs_match(_abi.ENV_ORI, env, orc.buf)
+    # a NaN action poisons only its own environment and raises the NaN status bit; nothing hangs
+    b = np.zeros((n, 6), np.float32)
+    b[5, 2] = np.nan
+    env.step(torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    status = np_(env.buf["status"])
+    assert status[5] & _abi.STATUS_NAN and not np.isfinite(np_(env.buf["reward"])[5])
+    ok = np.ones(n, bool)
+    ok[5] = False
+    assert np.isfinite(np_(env.buf["reward"])[ok]).all() and not status[ok].any()
+    env.close()
+
+
+def test_set_goal_and_obstacle_parity(oracle):
+    """a13: Reach*.set_goal / set_goal_and_obstacle (reach.py:202-204, 328-335, 702-713), model_test.py usage."""
+    rng = np.random.default_rng(5)
+    for env_id, kind, width in (("UR5ObsReach-v1", _abi.ENV_OBS, 9), ("UR5DynReach-v1", _abi.ENV_DYN, 18)):
+        n = 96
+        env = make_vec(env_id, num_envs=n, seed=2)
+        orc = oracle.OracleEnv(kind, n)
+        env.reset(seed=2)
+        orc.reset(seed=2)
+        ids = np.array([0, 5, 64, 95])
+        if kind == _abi.ENV_OBS:
+            data = np.c_[rng.uniform([0.3, -0.5, -0.1], [0.75, 0.5, 0.2], (4, 3)), rng.uniform([0.5, -0.5, 0.25], [1.0, 0.5, 0.55], (4, 3)),
+                         rng.uniform(-2.6, 2.6, (4, 2)), np.zeros(4)]
+            orc.buf["goal"][:3, ids] = data[:, :3].T
+            orc.buf["obst_start"][:, ids] = data[:, 3:9].T
+        else:
+            pose = lambda: np.c_[rng.uniform([0.5, -0.8, 0.25], [1.2, 0.8, 0.75], (4, 3)), rng.uniform(-2.6, 2.6, (4, 2)), np.zeros(4)]
+            data = np.c_[rng.uniform([0.4, -0.5, 0.0], [0.75, 0.5, 0.2], (4, 3)), np.deg2rad(rng.uniform(-180, -90, 4)), np.zeros(4),
+                         np.deg2rad(rng.uniform(-180, 0, 4)), pose(), pose()]
+            orc.buf["goal"][:, ids] = data[:, :6].T
+            orc.buf["obst_start"][:, ids] = data[:, 6:12].T
+            orc.buf["obst_end"][:, ids] = data[:, 12:18].T
+        assert data.shape[1] == width
+        mask = np.zeros(n, np.uint8)
+        mask[ids] = 1
+        orc.refresh(mask)
+        env.set_goal_and_obstacle(ids, data)
+        torch.cuda.synchronize()
+        st = env.get_state()
+        assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
+        assert np.abs(st["obst_vel"] - orc.buf["obst_vel"]).max() < 1e-12
+        assert obs_diff(kind, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
+        assert np.array_equal(np_(env.buf["collision"]), orc.buf["collision"])
+        # and the episode continues identically from there
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        env.step(torch.from_numpy(a).cuda())
+        orc.step(a)
+        torch.cuda.synchronize()
+        assert_outputs_match(kind, env, orc.buf)
+        env.close()
+    env = make_vec("UR5OriReach-v1", num_envs=8, seed=2)
+    env.reset()
+    env.set_goal([1, 2], [[0.5, 0.1, 0.1, -2.0, 0.0, -1.0], [0.6, -0.2, 0.05, -3.0, 0.0, -0.3]])
+    torch.cuda.synchronize()
+    assert np.allclose(np_(env.buf["observation"])[1, 12:18], [0.5, 0.1, 0.1, -2.0, 0.0, -1.0])
+    env.close()
+
+
+def test_rollout_equals_stepwise():
+    n, k = 256, 15
+    a = torch.rand((k, n, 6), device="cuda:0") * 2 - 1
+    e1 = make_vec("UR5DynReach-v1", num_envs=n, seed=9)
+    e2 = make_vec("UR5DynReach-v1", num_envs=n, seed=9)
+    e1.reset(seed=9)
+    e2.reset(seed=9)
+    for t in range(k):
+        e1.step(a[t])
+    e2.rollout(a)
+    torch.cuda.synchronize()
+    for key in ("observation", "reward", "terminated", "truncated", "q", "link_dist", "step_count", "episode_id"):
+        assert torch.equal(e1.buf[key], e2.buf[key]), key
+    e1.close()
+    e2.close()
+
+
+def test_full_size_properties():
+    """BASELINE.json configs[3]: UR5DynReach-v1, N=65536 — properties that need no oracle."""
+    n = 65536
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=0)
+    obs, info = env.reset(seed=0)
+    torch.cuda.synchronize()
+    # reset invariants: neutral joints, rejection rules of reach.py:668-675, fresh distances positive
+    assert torch.all(env.buf["q"].T == torch.tensor([0.0, -1.5708, 0.0, -1.5708, 0.0, 0.0], dtype=torch.float64, device="cuda:0"))
+    travel = (env.buf["obst_end"][:3] - env.buf["obst_start"][:3]).norm(dim=0)
+    assert travel.min() >= 1.0
+    assert env.buf["link_dist"].min() > 0.01 and not env.buf["status"].any()
+    g = env.buf["goal"]
+    assert g[0].min() >= 0.4 and g[0].max() <= 0.75 and g[2].min() >= 0.0 and g[2].max() <= 0.2
+    gen = torch.Generator(device="cuda:0")
+    gen.manual_seed(1)
+    acts = torch.rand((30, n, 6), generator=gen, device="cuda:0") * 2 - 1
+    ep0 = env.buf["episode_id"].clone()
+    for t in range(30):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        done = term | trunc
+        # auto-reset invariants: finished envs are back at step 0 in the neutral pose, others advanced by one
+        sc = env.buf["step_count"]
+        assert torch.all(sc[done] == 0) and torch.all(sc[~done] >= 1)
+        assert torch.all(obs["observation"].abs() <= 10.0)  # Box(-10, 10) of core.py:241-247
+        assert torch.all(rew[term & info["collision"]] == -500.0)
+        assert torch.all(rew[term & ~info["collision"]] == 200.0)
+        assert torch.all(info["is_success"] == (term & ~info["collision"]))
+    torch.cuda.synchronize()
+    assert torch.all(env.buf["episode_id"] >= ep0) and (env.buf["episode_id"] > ep0).any()
+    assert not (env.buf["status"] & ~_abi.STATUS_PENETRATION).any()
+    # determinism: a second instance with the same seed and actions ends in the identical state
+    env2 = make_vec("UR5DynReach-v1", num_envs=n, seed=0)
+    env2.reset(seed=0)
+    env2.rollout(acts)
+    torch.cuda.synchronize()
+    for key in ("observation", "reward", "q", "link_dist", "obst_pos", "step_count", "episode_id"):
+        assert torch.equal(env.buf[key], env2.buf[key]), key
+    # batch-position independence: replicate env 0's state into every slot -> every row steps identically
+    st = {k: v for k, v in env2.get_state().items()}
+    for k, v in st.items():
+        v[...] = v[..., :1]
+    env3 = make_vec("UR5DynReach-v1", num_envs=n, seed=0, auto_reset=False)
+    env3.set_state(st)
+    env3.buf["observation"][:] = env2.buf["observation"][0]
+    a = acts[0, :1].expand(n, 6).contiguous()
+    obs, rew, term, trunc, _ = env3.step(a)
+    torch.cuda.synchronize()
+    assert torch.all(obs["observation"] == obs["observation"][0]) and torch.all(rew == rew[0])
+    assert torch.all(term == term[0]) and torch.all(env3.buf["link_dist"] == env3.buf["link_dist"][:, :1])
+    env.close()
+    env2.close()
+    env3.close()

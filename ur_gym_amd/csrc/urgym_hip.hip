@@ -347,18 +347,20 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   // ---- P1: state, joint update, obstacle motion, FK to link L, culling, pose of hull L in the obstacle frame
   X3 Trel = identity_x3();
   D3 v0_obst = d3(0, 1, 0);  // world +Y (Bullet's initial separating axis) seen from the obstacle frame
+  bool finite = true;
   if (active) {
     double q[6];
     for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
     if (MODE == MODE_STEP) {
       for (int i = 0; i < 6; i++) {
         float a = actions[(size_t)n * 6 + i];
-        a = fminf(1.0f, fmaxf(-1.0f, a));
+        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);  // np.clip: a NaN action stays NaN (UR5.py:275)
         float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
         float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
         q[i] += (double)t2;
       }
     }
+    for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
     if (HAS_OBST) {
@@ -395,7 +397,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
         }
       }
     }
-    if (cfg.check_collision && MODE != MODE_RESET) {
+    if (cfg.check_collision && MODE != MODE_RESET && finite) {
       const double* c = c_tab.capsule[L - 1];
       D3 b0 = apply(TL, d3(c[0], c[1], c[2])), b1 = apply(TL, d3(c[3], c[4], c[5]));
       double rb = c[6];
@@ -448,7 +450,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       int e = lane;
       const bool obst_round = HAS_OBST && round == 0;
       if (obst_round) {
-        have = active;
+        have = active && finite;
         sa = hull_desc(L);
         sb = cyl_desc();
         Tab = Trel;
@@ -498,7 +500,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
           if (hit) atomicOr(&s_coll[e], 1);
         }
       } else if (obst_round) {
-        s_dist[wv][lane] = 1e30;
+        s_dist[wv][lane] = (active && !finite) ? __builtin_nan("") : 1e30;
       }
     }
   }
