@@ -1,0 +1,37 @@
+// Host harness: the DEVICE GJK (ur_gym_amd/csrc/urgym_device.h) compiled with g++ so that tests can run it on the CPU
+// against the oracle over hundreds of thousands of random queries.  Test infrastructure only.
+#define URGYM_HOST_HARNESS 1
+#include "../ur_gym_amd/csrc/urgym_device.h"
+#include "../data/ur5e_model.h"
+
+using namespace urgym;
+
+static X3 pose_to_x3(const double* p) {
+  X3 T;
+  quat_to_rot(Q4{p[3], p[4], p[5], p[6]}, T.r);
+  T.t = d3(p[0], p[1], p[2]);
+  return T;
+}
+static ShapeDesc desc(int type, const double* par, double* margin) {
+  ShapeDesc s;
+  s.type = type; s.hull = 0; s.hx = s.hy = s.hz = 0;
+  auto safe = [](double a, double b, double c) { double m = fmin(a, fmin(b, c)) * 0.1; return m < 0.04 ? m : 0.04; };
+  if (type == SH_HULL) { s.hull = (int)par[0] - 1; *margin = 0.001; }
+  else if (type == SH_CYLZ) { double m = safe(par[0], par[0], 0.5 * par[1]); s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; *margin = m; }
+  else if (type == SH_BOX) { double m = safe(par[0], par[1], par[2]); s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; *margin = m; }
+  else { *margin = par[0]; }
+  return s;
+}
+
+extern "C" int harness_closest(int type_a, const double* par_a, const double* pose_a, int type_b, const double* par_b,
+                               const double* pose_b, double threshold, double* out) {
+  HullGraph g{&UR5E_HULL_VERTS[0][0], UR5E_ADJ_OFFSET, UR5E_ADJ_INDEX, &UR5E_SEEDS[0][0]};
+  double ma, mb;
+  ShapeDesc A = desc(type_a, par_a, &ma), B = desc(type_b, par_b, &mb);
+  X3 Ta = pose_to_x3(pose_a), Tb = pose_to_x3(pose_b);
+  int info;
+  double core = gjk_core_distance(g, A, rel(Tb, Ta), B, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
+  out[0] = core - ma - mb;
+  out[1] = info;
+  return 0;
+}

@@ -31,7 +31,7 @@ def main():
         out["reset_observation"] = env.buf["observation"].copy()
         acts = (rng.uniform(-1, 1, (K, N, 6)) * rng.choice([0.3, 1.0, 1.7], (K, N, 1))).astype(np.float32)  # some beyond +-1: clipped
         rec = {k: [] for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success",
-                               "collision", "final_observation", "link_dist", "q")}
+                               "collision", "final_observation", "link_dist", "q", "obst_pos", "obst_quat")}
         for t in range(K):
             env.step(acts[t])
             for k in rec:

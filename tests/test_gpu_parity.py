@@ -3,11 +3,13 @@ liburgym_hip.so), against the CPU oracle on the same seeded inputs, against the 
 BASELINE.json's full size — through size-independent properties.
 
 Tolerances (written here, north_star: "within 1e-4 abs"):
-  observation / achieved / desired   1e-4 abs  (measured: ~1e-6; Euler angles compared modulo 2*pi: atan2 branch cut)
-  link distances (state)             2e-6 abs  (float32 support scan: a near-tied vertex can change Bullet's early-exit
-                                               path, ~1 query in 1e4; DESIGN.md "Precision")
-  reward                             1e-4 abs for Ori / Dyn; 3e-4 abs for Obs, whose 100x weight on the link-distance
-                                               change (reach.py:371) amplifies that 2e-6
+  observation / achieved / desired   1e-4 abs  (measured: <= 1e-6; Euler angles compared modulo 2*pi: atan2 branch cut)
+  link distances (state)             1e-8 abs  — EXCEPT at ill-conditioned queries (about 6 in 1e4): there the reference
+                                     algorithm itself (Bullet GJK, sliver-tetrahedron exit) is discontinuous and the
+                                     ORACLE's own answer jumps between 2-3 values ~1e-6..1e-5 apart under a 1e-14
+                                     perturbation of the pose.  At such a query the HIP value must lie inside the range
+                                     the oracle produces under that perturbation (checked explicitly below).
+  reward                             1e-4 abs + sum_i w_i * |that link-distance difference| (w <= 30.8 Dyn, 100 Obs)
   flags (terminated/truncated/is_success/collision), step counters: exact
 """
 import os
@@ -23,8 +25,8 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 KINDS = [("UR5OriReach-v1", _abi.ENV_ORI), ("UR5ObsReach-v1", _abi.ENV_OBS), ("UR5DynReach-v1", _abi.ENV_DYN)]
 EULER_COLS = {_abi.ENV_ORI: [3, 4, 5], _abi.ENV_OBS: [3, 4, 5], _abi.ENV_DYN: [3, 4, 5, 21, 22, 23]}
-REWARD_TOL = {_abi.ENV_ORI: 1e-4, _abi.ENV_OBS: 3e-4, _abi.ENV_DYN: 1e-4}
-OBS_TOL, LD_TOL = 1e-4, 2e-6
+REWARD_TOL = 1e-4
+OBS_TOL, LD_TOL = 1e-4, 1e-8
 STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist", "step_count", "episode_id")
 
 
@@ -45,14 +47,57 @@ def obs_diff(kind, a, b):
     return float(d.max()) if d.size else 0.0
 
 
-def assert_outputs_match(kind, env, ref, where=""):
+def link_dist_slack(oracle, gpu_ld, ref_ld, q, obst_pos, obst_quat):
+    """Per-env allowance for |gpu - oracle| link distances [5, N]: zero where they agree to LD_TOL; where they do not,
+    the query must be one at which the oracle itself is unstable — re-run the oracle under 1e-14 pose perturbations and
+    require the HIP value inside the range of its answers.  Returns the measured |difference| (0 where within LD_TOL)."""
+    diff = np.abs(gpu_ld - ref_ld)
+    slack = np.where(diff > LD_TOL, diff, 0.0)
+    rng = np.random.default_rng(0)
+    for i, n in zip(*np.nonzero(diff > LD_TOL)):
+        vals = []
+        for _ in range(200):
+            pose = np.r_[obst_pos[:, n] + rng.normal(0, 1e-14, 3), obst_quat[:, n]]
+            vals.append(oracle.query(q[:, n], pose)[0][i])
+        lo, hi = min(vals), max(vals)
+        assert hi - lo >= 0.9 * diff[i, n], f"link {i + 2} env {n}: differs by {diff[i, n]:.3e} at a WELL-conditioned query (oracle spread {hi - lo:.3e})"
+        assert lo - 1e-8 <= gpu_ld[i, n] <= hi + 1e-8, f"link {i + 2} env {n}: {gpu_ld[i, n]} outside the oracle's range [{lo}, {hi}]"
+    return slack
+
+
+def assert_outputs_match(kind, env, ref, where="", reward_slack=None):
     """ref: dict of numpy arrays (oracle buffers or a golden record)."""
     assert obs_diff(kind, np_(env.buf["observation"]), ref["observation"]) < OBS_TOL, where
     assert obs_diff(kind, np_(env.buf["achieved_goal"]), ref["achieved_goal"]) < OBS_TOL, where
     assert np.abs(np_(env.buf["desired_goal"]) - ref["desired_goal"]).max() < 1e-6, where
-    assert np.abs(np_(env.buf["reward"]) - ref["reward"]).max() < REWARD_TOL[kind], where
+    tol = REWARD_TOL + (0.0 if reward_slack is None else reward_slack)
+    assert np.all(np.abs(np_(env.buf["reward"]) - ref["reward"]) < tol), where
     for k in ("terminated", "truncated", "is_success", "collision"):
         assert np.array_equal(np_(env.buf[k]), ref[k]), (where, k)
+
+
+def step_both(oracle, kind, env, orc, a, where=""):
+    """Step the HIP env and the oracle with the same actions and compare EVERYTHING; link distances through
+    link_dist_slack (then resynchronised so that a legitimately different branch cannot cascade)."""
+    env.step(torch.from_numpy(a).cuda())
+    orc.step(a)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    assert np.abs(st["q"] - orc.buf["q"]).max() < 1e-12, where
+    assert np.array_equal(st["step_count"], orc.buf["step_count"]) and np.array_equal(st["episode_id"], orc.buf["episode_id"]), where
+    reward_slack, n_unstable = None, 0
+    if kind != _abi.ENV_ORI:
+        assert np.abs(st["obst_pos"] - orc.buf["obst_pos"]).max() < 1e-12, where
+        assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12, where
+        slack = link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"])
+        n_unstable = int((slack > 0).sum())
+        reward_slack = float(max(orc.cfg.w_link)) * slack.sum(0)
+        env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())
+    assert_outputs_match(kind, env, orc.buf, where=where, reward_slack=reward_slack)
+    done = (orc.buf["terminated"] | orc.buf["truncated"]).astype(bool)
+    if done.any():
+        assert obs_diff(kind, np_(env.buf["final_observation"])[done], orc.buf["final_observation"][done]) < OBS_TOL, where
+    return int(done.sum()), n_unstable
 
 
 @pytest.mark.parametrize("env_id,kind", KINDS)
@@ -67,7 +112,8 @@ def test_reset_parity(oracle, env_id, kind):
     for k in ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_vel"):
         assert np.abs(st[k] - orc.buf[k]).max() < 1e-12, k  # same Philox stream, same float64 formulas
     assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12
-    assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
+    if kind != _abi.ENV_ORI:
+        link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"])
     assert np.array_equal(st["step_count"], orc.buf["step_count"]) and np.array_equal(st["episode_id"], orc.buf["episode_id"])
     assert obs_diff(kind, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
@@ -93,31 +139,21 @@ def test_step_parity_against_oracle(oracle, env_id, kind):
     env.reset(seed=23)
     orc.reset(seed=23)
     rng = np.random.default_rng(23)
-    finished = 0
+    finished, unstable = 0, 0
     for t in range(steps):
         a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
-        env.step(torch.from_numpy(a).cuda())
-        orc.step(a)
-        torch.cuda.synchronize()
-        assert_outputs_match(kind, env, orc.buf, where=f"step {t}")
-        done = (orc.buf["terminated"] | orc.buf["truncated"]).astype(bool)
-        finished += int(done.sum())
-        if done.any():
-            assert obs_diff(kind, np_(env.buf["final_observation"])[done], orc.buf["final_observation"][done]) < OBS_TOL
-        st = env.get_state()
-        assert np.abs(st["q"] - orc.buf["q"]).max() < 1e-12
-        assert np.array_equal(st["step_count"], orc.buf["step_count"]) and np.array_equal(st["episode_id"], orc.buf["episode_id"])
-        if kind != _abi.ENV_ORI:
-            assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
-            assert np.abs(st["obst_pos"] - orc.buf["obst_pos"]).max() < 1e-12
-            assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12
+        d, u = step_both(oracle, kind, env, orc, a, where=f"step {t}")
+        finished += d
+        unstable += u
     assert finished > 20  # collisions / truncations did happen, so the auto-reset path was exercised
+    assert unstable < 1e-3 * steps * n * 5 + 3  # ill-conditioned queries are rare
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
     env.close()
 
 
 @pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2]])
-def test_golden_traces(name, env_id, kind):
+def test_golden_traces(oracle, name, env_id, kind):
+    """Committed vectors (tests/golden/step_trace_*.npz, produced by the oracle with gen_step_traces.py)."""
     g = np.load(os.path.join(HERE, "golden", f"step_trace_{name}.npz"))
     n = g["actions"].shape[1]
     env = make_vec(env_id, num_envs=n, seed=int(g["seed"]))
@@ -125,19 +161,28 @@ def test_golden_traces(name, env_id, kind):
     torch.cuda.synchronize()
     st = env.get_state()
     for k in STATE:
-        tol = LD_TOL if k == "link_dist" else 1e-12
-        assert np.abs(st[k].astype(np.float64) - g["reset_" + k]).max() <= tol, k
+        if k != "link_dist":
+            assert np.abs(st[k].astype(np.float64) - g["reset_" + k]).max() <= 1e-12, k
+    if kind != _abi.ENV_ORI:
+        link_dist_slack(oracle, st["link_dist"], g["reset_link_dist"], g["reset_q"], g["reset_obst_pos"], g["reset_obst_quat"])
     assert obs_diff(kind, np_(env.buf["observation"]), g["reset_observation"]) < OBS_TOL
+    w_max = {_abi.ENV_ORI: 0.0, _abi.ENV_OBS: 100.0, _abi.ENV_DYN: 8 / 13 * 50}[kind]
     for t in range(g["actions"].shape[0]):
         env.step(torch.from_numpy(g["actions"][t]).cuda())
         torch.cuda.synchronize()
         ref = {k: g["step_" + k][t] for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated",
                                                "truncated", "is_success", "collision")}
-        assert_outputs_match(kind, env, ref, where=f"golden step {t}")
+        reward_slack = None
+        if kind != _abi.ENV_ORI:
+            ld = np_(env.buf["link_dist"])
+            slack = link_dist_slack(oracle, ld, g["step_link_dist"][t], g["step_q"][t], g["step_obst_pos"][t], g["step_obst_quat"][t])
+            reward_slack = w_max * slack.sum(0)
+            env.buf["link_dist"].copy_(torch.from_numpy(g["step_link_dist"][t]).cuda())
+        assert_outputs_match(kind, env, ref, where=f"golden step {t}", reward_slack=reward_slack)
     st = env.get_state()
     for k in STATE:
-        tol = LD_TOL if k == "link_dist" else 1e-12
-        assert np.abs(st[k].astype(np.float64) - g["final_" + k]).max() <= tol, k
+        if k != "link_dist":
+            assert np.abs(st[k].astype(np.float64) - g["final_" + k]).max() <= 1e-12, k
     env.close()
 
 
@@ -150,10 +195,7 @@ def test_ragged_sizes(oracle, n):
     rng = np.random.default_rng(n)
     for t in range(12):
         a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
-        env.step(torch.from_numpy(a).cuda())
-        orc.step(a)
-        torch.cuda.synchronize()
-        assert_outputs_match(_abi.ENV_DYN, env, orc.buf, where=f"n={n} step {t}")
+        step_both(oracle, _abi.ENV_DYN, env, orc, a, where=f"n={n} step {t}")
     env.close()
 
 
@@ -210,16 +252,14 @@ def test_set_goal_and_obstacle_parity(oracle):
         env.set_goal_and_obstacle(ids, data)
         torch.cuda.synchronize()
         st = env.get_state()
-        assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < LD_TOL
+        link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"])
+        env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())
         assert np.abs(st["obst_vel"] - orc.buf["obst_vel"]).max() < 1e-12
         assert obs_diff(kind, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
         assert np.array_equal(np_(env.buf["collision"]), orc.buf["collision"])
         # and the episode continues identically from there
         a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
-        env.step(torch.from_numpy(a).cuda())
-        orc.step(a)
-        torch.cuda.synchronize()
-        assert_outputs_match(kind, env, orc.buf)
+        step_both(oracle, kind, env, orc, a)
         env.close()
     env = make_vec("UR5OriReach-v1", num_envs=8, seed=2)
     env.reset()

@@ -111,6 +111,45 @@ def bounding_capsule(v):
     return p0, p1, rad
 
 
+def hull_adjacency(v):
+    """Vertex adjacency of the convex hull surface (Qhull triangulation, option Qt): every polytope edge is an edge of
+    the triangulation, so a vertex none of whose neighbours has a larger d.x is a global maximiser of d.x."""
+    hull = ConvexHull(v)
+    assert len(hull.vertices) == len(v), "every table vertex must be a hull vertex"
+    nbr = [set() for _ in range(len(v))]
+    for tri in hull.simplices:
+        for a in range(3):
+            for b in range(3):
+                if a != b:
+                    nbr[tri[a]].add(int(tri[b]))
+    return [sorted(s) for s in nbr]
+
+
+def farthest_point_seeds(v, k):
+    idx = [int(np.argmax(np.linalg.norm(v - v.mean(0), axis=1)))]
+    d = np.linalg.norm(v - v[idx[0]], axis=1)
+    while len(idx) < k:
+        i = int(np.argmax(d))
+        idx.append(i)
+        d = np.minimum(d, np.linalg.norm(v - v[i], axis=1))
+    return idx
+
+
+def climb(v, nbr, seeds, d):
+    cur = seeds[int(np.argmax(v[seeds] @ d))]
+    best = v[cur] @ d
+    steps = 0
+    while True:
+        cand = nbr[cur]
+        t = v[cand] @ d
+        j = int(np.argmax(t))
+        if t[j] > best:
+            best, cur = t[j], cand[j]
+            steps += 1
+        else:
+            return cur, steps
+
+
 def fmt(x):
     return repr(float(x))
 
@@ -143,6 +182,9 @@ def main():
     assert all(float(t) == 0.0 for t in (eo.get("xyz") + " " + eo.get("rpy")).split())
 
     hull_off, hull_verts, caps, raw_counts = [0], [], [], []
+    adj_lists, seeds_all = [], []
+    NSEED = 16
+    rng = np.random.default_rng(0)
     for idx, lname, stl in LINKS:
         col = links[lname].find("collision")
         o = col.find("origin")
@@ -159,16 +201,34 @@ def main():
         hull_verts.append(v_link)
         hull_off.append(hull_off[-1] + len(v_link))
         caps.append(bounding_capsule(v_link))
+        nbr = hull_adjacency(v_link)
+        seeds = farthest_point_seeds(v_link, NSEED)
+        # offline proof-by-test of the hill-climbing support: equals the brute-force arg-max for random directions
+        worst_steps, tot = 0, 0
+        for _ in range(20000):
+            d = rng.normal(size=3)
+            cur, steps = climb(v_link, nbr, seeds, d)
+            assert v_link[cur] @ d >= (v_link @ d).max() - 1e-15 * np.linalg.norm(d), "hill climbing missed the support vertex"
+            worst_steps = max(worst_steps, steps)
+            tot += steps
+        deg = [len(x) for x in nbr]
+        print(f"   adjacency: degree mean {np.mean(deg):.1f} max {max(deg)}; climb steps from {NSEED} seeds: mean {tot/20000:.2f} max {worst_steps}")
+        base = hull_off[-2]
+        adj_lists += [[base + j for j in x] for x in nbr]
+        seeds_all.append([base + j for j in seeds])
         print(f"link {idx} {lname}: stl unique {len(pts)} -> bullet-quantised hull {len(v_link)} verts, "
               f"capsule r={caps[-1][2]:.4f} len={np.linalg.norm(caps[-1][1]-caps[-1][0]):.4f}")
     allv = np.concatenate(hull_verts)
+    adj_off = np.cumsum([0] + [len(x) for x in adj_lists]).astype(np.int32)
+    adj_idx = np.array([j for x in adj_lists for j in x], dtype=np.uint16)
 
     os.makedirs(args.out, exist_ok=True)
     np.savez(os.path.join(args.out, "ur5e_model.npz"),
              joint_xyz=np.array(jxyz), joint_rpy=np.array(jrpy), joint_rot=np.array(jrot), joint_limits=np.array(jlim),
              hull_offset=np.array(hull_off, dtype=np.int32), hull_verts=allv,
              capsule_p0=np.array([c[0] for c in caps]), capsule_p1=np.array([c[1] for c in caps]),
-             capsule_r=np.array([c[2] for c in caps]))
+             capsule_r=np.array([c[2] for c in caps]), adj_offset=adj_off, adj_index=adj_idx,
+             seeds=np.array(seeds_all, dtype=np.int32))
 
     with open(os.path.join(args.out, "ur5e_model.h"), "w") as f:
         f.write("/* GENERATED by tools/gen_model.py from the reference's ur5e.urdf and collision STLs (data tables only).\n"
@@ -186,6 +246,13 @@ def main():
         f.write("static const int UR5E_HULL_OFFSET[7] = {" + ", ".join(str(x) for x in hull_off) + "};\n")
         f.write("static const double UR5E_CAPSULE[6][7] = { /* p0.xyz, p1.xyz, radius (link frame) */\n" + ",\n".join(
             "  {" + ", ".join(fmt(x) for x in list(c[0]) + list(c[1]) + [c[2]]) + "}" for c in caps) + "\n};\n")
+        f.write(f"#define UR5E_NUM_ADJ {len(adj_idx)}\n#define UR5E_NUM_SEEDS {NSEED}\n")
+        f.write("/* hull surface graph (CSR over GLOBAL vertex ids): neighbours of vertex i = UR5E_ADJ_INDEX[UR5E_ADJ_OFFSET[i] .. UR5E_ADJ_OFFSET[i+1]) */\n")
+        f.write(f"static const int UR5E_ADJ_OFFSET[{len(adj_off)}] = {{" + ", ".join(str(int(x)) for x in adj_off) + "};\n")
+        f.write(f"static const unsigned short UR5E_ADJ_INDEX[{len(adj_idx)}] = {{" + ", ".join(str(int(x)) for x in adj_idx) + "};\n")
+        f.write("/* well-spread start vertices (global ids) for the hill-climbing support search */\n")
+        f.write(f"static const unsigned short UR5E_SEEDS[6][{NSEED}] = {{\n" + ",\n".join(
+            "  {" + ", ".join(str(int(x)) for x in r) + "}" for r in seeds_all) + "\n};\n")
         f.write(f"static const double UR5E_HULL_VERTS[{len(allv)}][3] = {{\n")
         f.write(",\n".join("  {" + ", ".join(fmt(x) for x in r) + "}" for r in allv))
         f.write("\n};\n\n#endif\n")

@@ -1,13 +1,22 @@
 // urgym_device.h — device-side math for the fused UR5e reach kernels (gfx950 only).
 //
-// Numeric plan: everything that the reference evaluates in float64 and that feeds an
-// output with a large weight (FK chain, Euler/quaternion conversions, pose distances, the GJK simplex) is done in
-// float64 here as well; only the O(#vertices) support scan over a convex hull runs in float32 on LDS-resident
-// vertices (it only has to pick the right vertex — the vertex is then re-read from the float64 table in global
-// memory (L2-resident, one 24-byte read per support call) and transformed in float64).
+// Numeric plan: the reference evaluates this path in float64 (pybullet's double build, numpy,
+// scipy) and casts to float32 only at the observation boundary, so the device does the same: FK chain, Euler /
+// quaternion conversions, pose distances, the GJK simplex AND the hull support search are float64.  The support
+// search stays cheap because it walks the hull's surface graph instead of scanning every vertex.
 #pragma once
-#include <hip/hip_runtime.h>
 #include <stdint.h>
+#if defined(URGYM_HOST_HARNESS)
+// tests/device_harness.cpp compiles this very header with g++ to run the device algorithms on the CPU next to the
+// oracle (debugging aid for parity work; never part of the product build)
+#include <cmath>
+#define __device__
+#define __forceinline__ inline
+static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+using std::fma; using std::sqrt; using std::fabs; using std::fmin; using std::fmax; using std::acos; using std::asin; using std::atan2;
+#else
+#include <hip/hip_runtime.h>
+#endif
 
 namespace urgym {
 
@@ -155,52 +164,61 @@ __device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (
 enum { SH_HULL = 0, SH_CYLZ = 1, SH_BOX = 2, SH_POINT = 3 };
 struct ShapeDesc {
   int type;
-  int blk_off;  // hull: first 4-vertex block in the LDS table
-  int nblk;     // hull: number of 4-vertex blocks
-  int vert_off; // hull: first vertex in the float64 vertex table (global memory)
-  int nverts;   // hull: number of vertices
+  int hull;           // SH_HULL: 0..5 = PyBullet link 1..6
   double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
-  D3 center;    // a point inside (initial direction only)
 };
 
-// LDS hull table layout: block b (4 vertices) = { x0..x3, y0..y3, z0..z3 } -> three 16-byte reads per block.
-// Scan = two-level arg-max: per block max of 4 dots, compared once against the running best; the winning block
-// is re-read afterwards to recover the vertex.  4.25 VALU ops per vertex instead of 6.
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const v4f* lds_f4_ptr;  // explicit LDS pointer: ds_read_b128, never flat
+// Convex-hull tables in global memory (L2-resident, ~130 KB in total, shared by every workgroup):
+//   verts[i]        exact float64 link-frame vertex i (global id)
+//   adj_off/adj_idx CSR surface graph of each hull (Qhull triangulation): neighbours of vertex i
+//   seeds[h][16]    well-spread start vertices of hull h
+struct HullGraph {
+  const double* __restrict__ verts;
+  const int* __restrict__ adj_off;
+  const unsigned short* __restrict__ adj_idx;
+  const unsigned short* __restrict__ seeds;
+};
+constexpr int HULL_SEEDS = 16;
 
-// Returns the index (within the hull) of the supporting vertex; the caller re-reads that vertex in float64.
-__device__ __forceinline__ int hull_support(lds_f4_ptr tab, int blk_off, int nblk, float dx, float dy, float dz) {
-  lds_f4_ptr t4 = tab + blk_off * 3;
-  float best = -3.0e38f;
-  int bb = 0;
-  for (int b = 0; b < nblk; b++) {
-    v4f X = t4[b * 3 + 0], Y = t4[b * 3 + 1], Z = t4[b * 3 + 2];
-    float t0 = fmaf(Z.x, dz, fmaf(Y.x, dy, X.x * dx));
-    float t1 = fmaf(Z.y, dz, fmaf(Y.y, dy, X.y * dx));
-    float t2 = fmaf(Z.z, dz, fmaf(Y.z, dy, X.z * dx));
-    float t3 = fmaf(Z.w, dz, fmaf(Y.w, dy, X.w * dx));
-    float m = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
-    bool g = m > best;
-    best = g ? m : best;
-    bb = g ? b : bb;
+// d . v evaluated exactly like the oracle's scan ((x*dx + y*dy) + z*dz, no fused ops) so that near-tied vertices are
+// ranked identically on both sides.
+__device__ __forceinline__ double vdot(const double* __restrict__ p, D3 d) { return (p[0] * d.x + p[1] * d.y) + p[2] * d.z; }
+
+// Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
+// On a convex polytope a vertex with no better neighbour is a global maximiser of the linear function, so this is
+// the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph) at ~20-40 dot
+// products instead of one per vertex.  `cur` carries the previous answer of this GJK run (warm start); -1 = none.
+__device__ __forceinline__ int hull_support_climb(const HullGraph& g, int h, D3 d, int cur) {
+  double best;
+  if (cur < 0) {
+    best = -1.0e300;
+#pragma unroll 4
+    for (int s = 0; s < HULL_SEEDS; s++) {
+      const int i = g.seeds[h * HULL_SEEDS + s];
+      const double t = vdot(g.verts + 3 * i, d);
+      if (t > best) { best = t; cur = i; }
+    }
+  } else {
+    best = vdot(g.verts + 3 * cur, d);
   }
-  v4f X = t4[bb * 3 + 0], Y = t4[bb * 3 + 1], Z = t4[bb * 3 + 2];
-  float t0 = fmaf(Z.x, dz, fmaf(Y.x, dy, X.x * dx));
-  float t1 = fmaf(Z.y, dz, fmaf(Y.y, dy, X.y * dx));
-  float t2 = fmaf(Z.z, dz, fmaf(Y.z, dy, X.z * dx));
-  int j = 3;
-  if (t2 >= best) j = 2;
-  if (t1 >= best) j = 1;
-  if (t0 >= best) j = 0;
-  return bb * 4 + j;
+  for (;;) {
+    const int o0 = g.adj_off[cur], o1 = g.adj_off[cur + 1];
+    int nxt = cur;
+    for (int e = o0; e < o1; e++) {
+      const int nb = g.adj_idx[e];
+      const double t = vdot(g.verts + 3 * nb, d);
+      if (t > best) { best = t; nxt = nb; }
+    }
+    if (nxt == cur) break;
+    cur = nxt;
+  }
+  return cur;
 }
 
-__device__ __forceinline__ D3 support_local(lds_f4_ptr tab, const double* __restrict__ verts64, const ShapeDesc& s, D3 d) {
+__device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d, int& cur) {
   if (s.type == SH_HULL) {
-    int i = hull_support(tab, s.blk_off, s.nblk, (float)d.x, (float)d.y, (float)d.z);
-    i = min(i, s.nverts - 1);  // the last LDS block is padded with copies of the last vertex
-    const double* p = verts64 + (size_t)(s.vert_off + i) * 3;
+    cur = hull_support_climb(g, s.hull, d, cur);
+    const double* p = g.verts + 3 * cur;
     return d3(p[0], p[1], p[2]);
   } else if (s.type == SH_CYLZ) {
     double sn = sqrt(d.x * d.x + d.y * d.y);
@@ -250,8 +268,8 @@ enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4 };
 //   max_d : Bullet's early-out distance (marginA + marginB + 0.02 + query threshold) on the core distance; when a
 //           separating axis proves the cores farther apart than that the search stops (GJK_SEPARATED).
 // Returns the core distance |v|; GJK_PENETRATING when the cores touch/overlap (Bullet would enter EPA).
-__device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const double* __restrict__ verts64, const ShapeDesc& A,
-                                                    const X3& T, const ShapeDesc& B, D3 v0, double max_d, int& info) {
+__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, const X3& T, const ShapeDesc& B,
+                                                    D3 v0, double max_d, int& info) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
   info = 0;
@@ -264,9 +282,10 @@ __device__ __forceinline__ double gjk_core_distance(lds_f4_ptr tab, const double
   bool check_simplex = false;
   int degenerate = 0;
   int iter = 0;
+  int curA = -1, curB = -1;  // warm starts of the two hull searches
   for (;;) {
-    D3 p = apply(T, support_local(tab, verts64, A, rotT(T, -v)));
-    D3 q = support_local(tab, verts64, B, v);
+    D3 p = apply(T, support_local(g, A, rotT(T, -v), curA));
+    D3 q = support_local(g, B, v, curB);
     D3 w = p - q;
     double delta = dot(v, w);
     if (delta > 0.0 && delta * delta > sq * max_d2) { degenerate = 10; check_simplex = true; break; }

@@ -34,7 +34,6 @@ namespace {
 constexpr int ENVS_PER_GROUP = 64;
 constexpr int WAVES = 5;
 constexpr int THREADS = ENVS_PER_GROUP * WAVES;
-constexpr int MAX_HULL_BLOCKS = (UR5E_NUM_HULL_VERTS + 3 * UR5E_NUM_HULLS) / 4 + 1;
 constexpr int QUEUE_CAP = ENVS_PER_GROUP * 19;
 
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2 };
@@ -54,17 +53,13 @@ struct DevTables {
   double joint_rot[6][9];
   double joint_xyz[6][3];
   double capsule[6][7];
-  int hull_blk_off[7];
-  int hull_vert_off[7];
 };
 __constant__ DevTables c_tab;
 
 struct KParams {
   urgym_config cfg;
   urgym_buffers buf;
-  const float* hull_table;  // packed 4-vertex blocks, MAX_HULL_BLOCKS * 12 floats
-  const double* hull_verts64;  // [UR5E_NUM_HULL_VERTS][3] exact link-frame vertices
-  int hull_blocks;
+  HullGraph graph;  // convex-hull vertex / adjacency / seed tables (device global memory)
   int obs_dim, goal_dim;
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
@@ -75,34 +70,24 @@ __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { retu
 
 __device__ __forceinline__ ShapeDesc hull_desc(int link /*1..6*/) {
   ShapeDesc s;
-  s.type = SH_HULL;
-  s.blk_off = c_tab.hull_blk_off[link - 1];
-  s.nblk = c_tab.hull_blk_off[link] - c_tab.hull_blk_off[link - 1];
-  s.vert_off = c_tab.hull_vert_off[link - 1];
-  s.nverts = c_tab.hull_vert_off[link] - c_tab.hull_vert_off[link - 1];
-  s.hx = s.hy = s.hz = 0.0;
-  const double* c = c_tab.capsule[link - 1];
-  s.center = d3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]));
+  s.type = SH_HULL; s.hull = link - 1; s.hx = s.hy = s.hz = 0.0;
   return s;
 }
 __device__ __forceinline__ ShapeDesc cyl_desc() {
   ShapeDesc s;
-  s.type = SH_CYLZ; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0;
+  s.type = SH_CYLZ; s.hull = 0;
   s.hx = s.hy = CYL_R - M_CYL; s.hz = 0.5 * CYL_H - M_CYL;
-  s.center = d3(0, 0, 0);
   return s;
 }
 __device__ __forceinline__ ShapeDesc box_desc(double hx, double hy, double hz, double margin) {
   ShapeDesc s;
-  s.type = SH_BOX; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0;
+  s.type = SH_BOX; s.hull = 0;
   s.hx = hx - margin; s.hy = hy - margin; s.hz = hz - margin;
-  s.center = d3(0, 0, 0);
   return s;
 }
 __device__ __forceinline__ ShapeDesc point_desc() {
   ShapeDesc s;
-  s.type = SH_POINT; s.blk_off = 0; s.nblk = 0; s.vert_off = 0; s.nverts = 0; s.hx = s.hy = s.hz = 0.0;
-  s.center = d3(0, 0, 0);
+  s.type = SH_POINT; s.hull = 0; s.hx = s.hy = s.hz = 0.0;
   return s;
 }
 
@@ -208,7 +193,7 @@ __device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const d
 
 // ---- RESET: one lane samples a new episode (reach.py:197-200, 313-326, 664-683; samplers utils.py:81-100)
 template <int KIND>
-__device__ void sample_episode(const KParams& P, lds_f4_ptr tab, int n, int& flags) {
+__device__ void sample_episode(const KParams& P, int n, int& flags) {
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
   const int N = cfg.num_envs;
@@ -267,7 +252,7 @@ __device__ void sample_episode(const KParams& P, lds_f4_ptr tab, int n, int& fla
       Tt.t = d3(goal[0], goal[1], goal[2]);
       int info;
       // Bullet's pair detector starts from the world +Y axis; B's frame is the obstacle's
-      double core = gjk_core_distance(tab, P.hull_verts64, ta, rel(To, Tt), cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
+      double core = gjk_core_distance(P.graph, ta, rel(To, Tt), cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
       double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
       fail = dist < cfg.target_clearance;
     }
@@ -287,7 +272,7 @@ __device__ void sample_episode(const KParams& P, lds_f4_ptr tab, int n, int& fla
 
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const float* __restrict__ actions) {
-  __shared__ float4 s_hull[MAX_HULL_BLOCKS * 3];
+  __shared__ float s_out[ENVS_PER_GROUP * 47];  // observation | achieved | desired rows staged for coalesced stores
   __shared__ double s_dist[WAVES][ENVS_PER_GROUP];
   __shared__ double s_q[6][ENVS_PER_GROUP];
   __shared__ double s_obst[7][ENVS_PER_GROUP];
@@ -295,8 +280,6 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   __shared__ int s_qcount;
   __shared__ int s_coll[ENVS_PER_GROUP];
   __shared__ int s_flags[ENVS_PER_GROUP];
-  float* const s_out = reinterpret_cast<float*>(s_hull);  // observation staging reuses the hull table after P3
-  static_assert(sizeof(float) * ENVS_PER_GROUP * 47 <= sizeof(float4) * MAX_HULL_BLOCKS * 3, "staging must fit");
 
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
@@ -325,19 +308,12 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   if (tid == 0) s_qcount = 0;
   if (tid < ENVS_PER_GROUP) { s_coll[tid] = 0; s_flags[tid] = 0; }
 
-  // ---- P0: hull table -> LDS
-  {
-    const float4* src = reinterpret_cast<const float4*>(P.hull_table);
-    const int total = P.hull_blocks * 3;
-    for (int i = tid; i < total; i += THREADS) s_hull[i] = src[i];
-  }
-  lds_f4_ptr tab = (lds_f4_ptr)(s_hull);
   __syncthreads();
 
   if (MODE == MODE_RESET) {
     if (wv == 0 && active) {
       int flags = 0;
-      sample_episode<KIND>(P, tab, n, flags);
+      sample_episode<KIND>(P, n, flags);
       if (flags) atomicOr(&s_flags[lane], flags);
     }
     __threadfence_block();
@@ -489,7 +465,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       }
       if (have) {
         int info;
-        const double core = gjk_core_distance(tab, P.hull_verts64, sa, Tab, sb, v0, max_d, info);
+        const double core = gjk_core_distance(P.graph, sa, Tab, sb, v0, max_d, info);
         if (obst_round) {
           double dist = core - msum;
           if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[lane], URGYM_STATUS_PENETRATION); }
@@ -715,9 +691,10 @@ struct Handle {
   bool bound = false;
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
-  float* d_hull = nullptr;
   double* d_verts64 = nullptr;
-  int hull_blocks = 0;
+  int* d_adj_off = nullptr;
+  unsigned short* d_adj_idx = nullptr;
+  unsigned short* d_seeds = nullptr;
   uint64_t seed = 0;
   int pp = 0;
   char err[512] = {0};
@@ -789,9 +766,10 @@ KParams make_params(Handle* h, int copy_final) {
   KParams P;
   P.cfg = h->cfg;
   P.buf = h->buf;
-  P.hull_table = h->d_hull;
-  P.hull_verts64 = h->d_verts64;
-  P.hull_blocks = h->hull_blocks;
+  P.graph.verts = h->d_verts64;
+  P.graph.adj_off = h->d_adj_off;
+  P.graph.adj_idx = h->d_adj_idx;
+  P.graph.seeds = h->d_seeds;
   P.obs_dim = h->obs_dim;
   P.goal_dim = h->goal_dim;
   P.seed_lo = (uint32_t)h->seed;
@@ -907,34 +885,26 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   memcpy(t.joint_rot, UR5E_JOINT_ROT, sizeof(t.joint_rot));
   memcpy(t.joint_xyz, UR5E_JOINT_XYZ, sizeof(t.joint_xyz));
   memcpy(t.capsule, UR5E_CAPSULE, sizeof(t.capsule));
-  std::vector<float> packed((size_t)MAX_HULL_BLOCKS * 12, 0.f);
-  int blk = 0;
-  for (int hidx = 0; hidx < 6; hidx++) {
-    t.hull_blk_off[hidx] = blk;
-    t.hull_vert_off[hidx] = UR5E_HULL_OFFSET[hidx];
-    int v0 = UR5E_HULL_OFFSET[hidx], v1 = UR5E_HULL_OFFSET[hidx + 1];
-    for (int v = v0; v < v1; v += 4, blk++) {
-      for (int j = 0; j < 4; j++) {
-        int vi = v + j < v1 ? v + j : v1 - 1;  // pad the last block by repeating the last vertex
-        packed[(size_t)blk * 12 + 0 + j] = (float)UR5E_HULL_VERTS[vi][0];
-        packed[(size_t)blk * 12 + 4 + j] = (float)UR5E_HULL_VERTS[vi][1];
-        packed[(size_t)blk * 12 + 8 + j] = (float)UR5E_HULL_VERTS[vi][2];
-      }
-    }
-  }
-  t.hull_blk_off[6] = blk;
-  t.hull_vert_off[6] = UR5E_HULL_OFFSET[6];
-  h->hull_blocks = blk;
-  if (blk > MAX_HULL_BLOCKS) { delete h; return fail(nullptr, URGYM_ERR_STATE, "hull table larger than the LDS budget"); }
+  static_assert(UR5E_NUM_SEEDS == HULL_SEEDS, "seed table width");
   e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
   if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpyToSymbol(c_tab)", e); }
-  e = hipMalloc(&h->d_hull, packed.size() * sizeof(float));
-  if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMalloc(hull table)", e); }
-  e = hipMemcpy(h->d_hull, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { hipFree(h->d_hull); delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpy(hull table)", e); }
-  e = hipMalloc(&h->d_verts64, sizeof(UR5E_HULL_VERTS));
-  if (e == hipSuccess) e = hipMemcpy(h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { hipFree(h->d_hull); if (h->d_verts64) hipFree(h->d_verts64); delete h; return fail(nullptr, URGYM_ERR_HIP, "hull vertex table upload", e); }
+  auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t r = hipMalloc(dst, bytes);
+    if (r != hipSuccess) return r;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
+  if (e == hipSuccess) e = upload((void**)&h->d_adj_off, UR5E_ADJ_OFFSET, sizeof(UR5E_ADJ_OFFSET));
+  if (e == hipSuccess) e = upload((void**)&h->d_adj_idx, UR5E_ADJ_INDEX, sizeof(UR5E_ADJ_INDEX));
+  if (e == hipSuccess) e = upload((void**)&h->d_seeds, UR5E_SEEDS, sizeof(UR5E_SEEDS));
+  if (e != hipSuccess) {
+    if (h->d_verts64) hipFree(h->d_verts64);
+    if (h->d_adj_off) hipFree(h->d_adj_off);
+    if (h->d_adj_idx) hipFree(h->d_adj_idx);
+    if (h->d_seeds) hipFree(h->d_seeds);
+    delete h;
+    return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
+  }
   *handle = h;
   return URGYM_OK;
 }
@@ -944,8 +914,10 @@ int urgym_destroy(void* handle) {
   if (!h) return URGYM_OK;
   hipSetDevice(h->device);
   for (auto e : h->ev) hipEventDestroy(e);
-  if (h->d_hull) hipFree(h->d_hull);
   if (h->d_verts64) hipFree(h->d_verts64);
+  if (h->d_adj_off) hipFree(h->d_adj_off);
+  if (h->d_adj_idx) hipFree(h->d_adj_idx);
+  if (h->d_seeds) hipFree(h->d_seeds);
   delete h;
   return URGYM_OK;
 }
