@@ -145,6 +145,13 @@ int urgym_rollout(void* handle, const float* actions_dev, int num_steps, void* s
  * velocity, collision, link_dist and the observation for them, leaving step_count untouched. */
 int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream);
 
+/* Unit probe of the device closest-distance routine (what p.getClosestPoints computes, pyb_setup.py:401-452): one query per
+ * entry, all pointers are DEVICE pointers.  type: 0 hull (par[0] = PyBullet link 1..6), 1 cylinder-Z (radius, height),
+ * 2 box (half extents), 3 sphere (radius); pose = xyz + quaternion xyzw; out_dist = signed distance incl. Bullet margins.
+ * Used by the parity tests to reach the hull<->box and hull<->hull paths directly. */
+int urgym_probe_closest(void* handle, int count, const int* type_a, const double* par_a, const double* pose_a, const int* type_b,
+                        const double* par_b, const double* pose_b, double threshold, double* out_dist, int* out_info, void* stream);
+
 /* Average device time (microseconds) of the step kernel over the calls since the last query, measured with
  * hipEvents on the launch stream; returns <0 if timing was not enabled. */
 int urgym_enable_timing(void* handle, int enable);

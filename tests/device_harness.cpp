@@ -2,7 +2,7 @@
 // against the oracle over hundreds of thousands of random queries.  Test infrastructure only.
 #define URGYM_HOST_HARNESS 1
 #include "../ur_gym_amd/csrc/urgym_device.h"
-#include "../data/ur5e_model.h"
+#include "../ur_gym_amd/csrc/urgym_tables_host.h"
 
 using namespace urgym;
 
@@ -25,7 +25,8 @@ static ShapeDesc desc(int type, const double* par, double* margin) {
 
 extern "C" int harness_closest(int type_a, const double* par_a, const double* pose_a, int type_b, const double* par_b,
                                const double* pose_b, double threshold, double* out) {
-  HullGraph g{&UR5E_HULL_VERTS[0][0], UR5E_ADJ_OFFSET, UR5E_ADJ_INDEX, &UR5E_SEEDS[0][0]};
+  static HostTables tabs = build_host_tables();
+  HullGraph g{&UR5E_HULL_VERTS[0][0], tabs.recs.data(), tabs.seeds};
   double ma, mb;
   ShapeDesc A = desc(type_a, par_a, &ma), B = desc(type_b, par_b, &mb);
   X3 Ta = pose_to_x3(pose_a), Tb = pose_to_x3(pose_b);

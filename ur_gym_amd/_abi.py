@@ -96,6 +96,7 @@ EXPORTED_SYMBOLS = [
     "urgym_step",
     "urgym_rollout",
     "urgym_refresh",
+    "urgym_probe_closest",
     "urgym_enable_timing",
     "urgym_query_timing",
     "urgym_last_error",

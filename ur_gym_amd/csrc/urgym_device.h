@@ -168,58 +168,76 @@ struct ShapeDesc {
   double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
 };
 
-// Convex-hull tables in global memory (L2-resident, ~130 KB in total, shared by every workgroup):
-//   verts[i]        exact float64 link-frame vertex i (global id)
-//   adj_off/adj_idx CSR surface graph of each hull (Qhull triangulation): neighbours of vertex i
-//   seeds[h][16]    well-spread start vertices of hull h
-struct HullGraph {
-  const double* __restrict__ verts;
-  const int* __restrict__ adj_off;
-  const unsigned short* __restrict__ adj_idx;
-  const unsigned short* __restrict__ seeds;
+// Convex-hull tables in global memory (L2-resident, < 1 MB, shared by every workgroup).
+// The surface graph of each hull (Qhull triangulation, data/ur5e_model.h) is stored as NEIGHBOUR RECORDS: record i
+// (i = global vertex id) holds the ids AND the exact float64 coordinates of up to 8 neighbours of vertex i, so one hill-
+// climbing step is a single round trip of wide, independent loads (224 contiguous bytes) instead of the dependent
+// chain offset -> ids -> coordinates.  Vertices with more than 8 neighbours chain further records through `next`;
+// unused slots repeat the vertex itself (never "better", the comparison is strict).
+struct NbrRec {
+  int next;               // next record of the same vertex, -1 = none
+  int pad[3];
+  unsigned short id[8];
+  double x[8], y[8], z[8];
 };
+static_assert(sizeof(NbrRec) == 224, "record layout");
 constexpr int HULL_SEEDS = 16;
+struct SeedRec {          // well-spread start vertices of one hull
+  int id[HULL_SEEDS];
+  double x[HULL_SEEDS], y[HULL_SEEDS], z[HULL_SEEDS];
+};
+struct HullGraph {
+  const double* __restrict__ verts;   // [NV][3] exact link-frame vertices
+  const NbrRec* __restrict__ recs;    // [NV + overflow]
+  const SeedRec* __restrict__ seeds;  // [6]
+};
 
 // d . v evaluated exactly like the oracle's scan ((x*dx + y*dy) + z*dz, no fused ops) so that near-tied vertices are
 // ranked identically on both sides.
-__device__ __forceinline__ double vdot(const double* __restrict__ p, D3 d) { return (p[0] * d.x + p[1] * d.y) + p[2] * d.z; }
+__device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) { return (x * d.x + y * d.y) + z * d.z; }
 
 // Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
 // On a convex polytope a vertex with no better neighbour is a global maximiser of the linear function, so this is
-// the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph) at ~20-40 dot
+// the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph) at ~16-32 dot
 // products instead of one per vertex.  `cur` carries the previous answer of this GJK run (warm start); -1 = none.
-__device__ __forceinline__ int hull_support_climb(const HullGraph& g, int h, D3 d, int cur) {
+__device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d, int& cur) {
   double best;
+  D3 pt;
   if (cur < 0) {
+    const SeedRec& S = g.seeds[h];
     best = -1.0e300;
-#pragma unroll 4
+    pt = d3(0, 0, 0);
+#pragma unroll
     for (int s = 0; s < HULL_SEEDS; s++) {
-      const int i = g.seeds[h * HULL_SEEDS + s];
-      const double t = vdot(g.verts + 3 * i, d);
-      if (t > best) { best = t; cur = i; }
+      const double t = vdot3(S.x[s], S.y[s], S.z[s], d);
+      if (t > best) { best = t; cur = S.id[s]; pt = d3(S.x[s], S.y[s], S.z[s]); }
     }
   } else {
-    best = vdot(g.verts + 3 * cur, d);
+    const double* p = g.verts + 3 * cur;
+    pt = d3(p[0], p[1], p[2]);
+    best = vdot3(pt.x, pt.y, pt.z, d);
   }
   for (;;) {
-    const int o0 = g.adj_off[cur], o1 = g.adj_off[cur + 1];
     int nxt = cur;
-    for (int e = o0; e < o1; e++) {
-      const int nb = g.adj_idx[e];
-      const double t = vdot(g.verts + 3 * nb, d);
-      if (t > best) { best = t; nxt = nb; }
-    }
+    int rec = cur;
+    do {
+      const NbrRec& R = g.recs[rec];
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const double t = vdot3(R.x[j], R.y[j], R.z[j], d);
+        if (t > best) { best = t; nxt = R.id[j]; pt = d3(R.x[j], R.y[j], R.z[j]); }
+      }
+      rec = R.next;
+    } while (rec >= 0);
     if (nxt == cur) break;
     cur = nxt;
   }
-  return cur;
+  return pt;
 }
 
 __device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d, int& cur) {
   if (s.type == SH_HULL) {
-    cur = hull_support_climb(g, s.hull, d, cur);
-    const double* p = g.verts + 3 * cur;
-    return d3(p[0], p[1], p[2]);
+    return hull_support_climb(g, s.hull, d, cur);
   } else if (s.type == SH_CYLZ) {
     double sn = sqrt(d.x * d.x + d.y * d.y);
     double hz = d.z < 0.0 ? -s.hz : s.hz;

@@ -26,6 +26,7 @@
 #include "../../include/urgym.h"
 #include "../../data/ur5e_model.h"
 #include "urgym_device.h"
+#include "urgym_tables_host.h"
 
 using namespace urgym;
 
@@ -274,12 +275,13 @@ template <int KIND, int MODE>
 __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const float* __restrict__ actions) {
   __shared__ float s_out[ENVS_PER_GROUP * 47];  // observation | achieved | desired rows staged for coalesced stores
   __shared__ double s_dist[WAVES][ENVS_PER_GROUP];
-  __shared__ double s_q[6][ENVS_PER_GROUP];
-  __shared__ double s_obst[7][ENVS_PER_GROUP];
+  __shared__ double s_q[6][ENVS_PER_GROUP];     // joint vector of the step (after the action)
+  __shared__ double s_obst[7][ENVS_PER_GROUP];  // obstacle position + quaternion of the step (after its motion)
   __shared__ uint32_t s_queue[QUEUE_CAP];
   __shared__ int s_qcount;
   __shared__ int s_coll[ENVS_PER_GROUP];
   __shared__ int s_flags[ENVS_PER_GROUP];
+  __shared__ int s_env[ENVS_PER_GROUP];         // global env id of slot e, -1 = empty slot
 
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
@@ -287,203 +289,179 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = wv + 2;  // PyBullet link index owned by this wave
   const int OD = P.obs_dim, GD = P.goal_dim;
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
 
-  // ---- which environment does this lane work on?
-  const int idx = blockIdx.x * ENVS_PER_GROUP + lane;
-  int n;
-  bool active;
   int list_count = 0;
-  if (MODE == MODE_STEP) {
-    n = idx;
-    active = idx < N;
-  } else {
+  if (MODE != MODE_STEP) {
     list_count = B.done_count[P.pp];
     if (blockIdx.x * ENVS_PER_GROUP >= list_count) return;  // uniform for the whole group
-    active = idx < list_count;
-    n = active ? B.done_list[idx] : 0;
-  }
-  if (tid == 0) s_qcount = 0;
-  if (tid < ENVS_PER_GROUP) { s_coll[tid] = 0; s_flags[tid] = 0; }
-
-  __syncthreads();
-
-  if (MODE == MODE_RESET) {
-    if (wv == 0 && active) {
-      int flags = 0;
-      sample_episode<KIND>(P, n, flags);
-      if (flags) atomicOr(&s_flags[lane], flags);
-    }
-    __threadfence_block();
-    __syncthreads();  // the sampled goal / obstacle (global memory) is visible to the other waves of this group
   }
 
-  // ---- P1: state, joint update, obstacle motion, FK to link L, culling, pose of hull L in the obstacle frame
-  X3 Trel = identity_x3();
-  D3 v0_obst = d3(0, 1, 0);  // world +Y (Bullet's initial separating axis) seen from the obstacle frame
-  bool finite = true;
-  if (active) {
-    double q[6];
-    for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
-    if (MODE == MODE_STEP) {
-      for (int i = 0; i < 6; i++) {
-        float a = actions[(size_t)n * 6 + i];
-        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);  // np.clip: a NaN action stays NaN (UR5.py:275)
-        float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
-        float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
-        q[i] += (double)t2;
-      }
-    }
-    for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
+  // ---- P1 (wave 0, one lane per env slot): which env, joint update, obstacle motion -> LDS
+  if (wv == 0) {
+    const int idx = blockIdx.x * ENVS_PER_GROUP + lane;
+    int n = -1;
+    if (MODE == MODE_STEP) n = idx < N ? idx : -1;
+    else n = idx < list_count ? B.done_list[idx] : -1;
+    int flags = 0;
+    if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, n, flags);  // writes goal / obstacle / q / episode_id
+    s_flags[lane] = flags;
+    s_coll[lane] = 0;
+    if (lane == 0) s_qcount = 0;
+    double q[6] = {0, 0, 0, 0, 0, 0};
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
-    if (HAS_OBST) {
+    bool finite = true;
+    if (n >= 0) {
+      for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
       if (MODE == MODE_STEP) {
-        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
-        oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
-        if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
-          double ovel[6];
-          for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
-          integrate_obstacle(opos, oq, ovel, cfg.dt);
-        }
-      } else {
-        // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
-        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
-        oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
-      }
-    }
-    if (wv == WAVES - 1) {
-      for (int i = 0; i < 6; i++) s_q[i][lane] = q[i];
-      s_obst[0][lane] = opos[0]; s_obst[1][lane] = opos[1]; s_obst[2][lane] = opos[2];
-      s_obst[3][lane] = oq.x; s_obst[4][lane] = oq.y; s_obst[5][lane] = oq.z; s_obst[6][lane] = oq.w;
-    }
-    // FK up to link L, remembering the world capsules of links 1..3 for the self-collision culling
-    X3 TL = identity_x3();
-    D3 capA0[3], capA1[3];
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-      if (k < L) {
-        fk_joint(TL, k, q[k]);
-        if (k < 3) {
-          const double* c = c_tab.capsule[k];
-          capA0[k] = apply(TL, d3(c[0], c[1], c[2]));
-          capA1[k] = apply(TL, d3(c[3], c[4], c[5]));
+        for (int i = 0; i < 6; i++) {
+          float a = actions[(size_t)n * 6 + i];
+          a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);   // np.clip: a NaN action stays NaN (UR5.py:275)
+          float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
+          float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
+          q[i] += (double)t2;
         }
       }
-    }
-    if (cfg.check_collision && MODE != MODE_RESET && finite) {
-      const double* c = c_tab.capsule[L - 1];
-      D3 b0 = apply(TL, d3(c[0], c[1], c[2])), b1 = apply(TL, d3(c[3], c[4], c[5]));
-      double rb = c[6];
-      const double lim = cfg.collision_margin + 1e-6;
-      if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim) {
-        int slot = atomicAdd(&s_qcount, 1);
-        s_queue[slot] = (uint32_t)lane | (Q_TABLE << 6) | ((uint32_t)L << 8);
-      }
-      if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim) {
-        int slot = atomicAdd(&s_qcount, 1);
-        s_queue[slot] = (uint32_t)lane | (Q_TRACK << 6) | ((uint32_t)L << 8);
-      }
-      // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6) -> handled by the wave of link B
-#pragma unroll
-      for (int A = 1; A <= 3; A++) {
-        if (A <= L - 2) {
-          double ra = c_tab.capsule[A - 1][6];
-          if (segseg_dist(capA0[A - 1], capA1[A - 1], b0, b1) - ra - rb <= lim) {
-            int slot = atomicAdd(&s_qcount, 1);
-            s_queue[slot] = (uint32_t)lane | (Q_SELF << 6) | ((uint32_t)L << 8) | ((uint32_t)A << 11);
+      for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
+      if (HAS_OBST) {
+        if (MODE == MODE_STEP) {
+          for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
+          oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
+          if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
+            double ovel[6];
+            for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
+            integrate_obstacle(opos, oq, ovel, cfg.dt);
           }
+        } else {
+          // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
+          for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
+          oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
         }
       }
     }
-    if (HAS_OBST) {
-      X3 To;
-      quat_to_rot(oq, To.r);
-      To.t = d3(opos[0], opos[1], opos[2]);
-      Trel = rel(To, TL);
-      v0_obst = rotT(To, d3(0, 1, 0));
-    }
+    s_env[lane] = (n >= 0 && finite) ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
+    for (int i = 0; i < 6; i++) s_q[i][lane] = q[i];
+    s_obst[0][lane] = opos[0]; s_obst[1][lane] = opos[1]; s_obst[2][lane] = opos[2];
+    s_obst[3][lane] = oq.x; s_obst[4][lane] = oq.y; s_obst[5][lane] = oq.z; s_obst[6][lane] = oq.w;
   }
   __syncthreads();
 
-  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined GJK body.
-  //   round 0  (envs with an obstacle): lane <-> exact distance hull(L) <-> obstacle cylinder (pyb_setup.py:439-456;
-  //            it also decides the obstacle part of check_collision, pyb_setup.py:397-405)
-  //   round 1+ : the (rare) table / track / self pairs that survived the capsule culling, one per lane across the
-  //            whole group; boolean "closer than the collision margin?" with early exit
+  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined GJK body.  Each work item rebuilds its
+  // transforms from the joint vector in LDS, so nothing but loop counters is live across the GJK.
+  //   round 0 : lane (env e, link L = wave + 2): float64 FK to link L, capsule culling of the table / track / self
+  //             pairs that involve L (pyb_setup.py:407-427; survivors -> LDS queue), then the exact distance
+  //             hull(L) <-> obstacle cylinder (pyb_setup.py:439-456, also the obstacle rule of check_collision)
+  //   round 1+: the queued (rare) pairs, one per lane across the whole group: boolean "closer than the margin?"
   {
-    const int qn = s_qcount;  // complete since the barrier after P1
-    const int first_q = HAS_OBST ? 1 : 0;
-    const int nrounds = first_q + (qn + THREADS - 1) / THREADS;
-    for (int round = 0; round < nrounds; round++) {
+    for (int round = 0;; round++) {
+      if (round == 1) __syncthreads();                         // the queue is complete
+      if (round >= 1 && (round - 1) * THREADS >= s_qcount) break;  // uniform: every thread reads the same count
+      uint32_t item;
       bool have;
-      ShapeDesc sa, sb;
-      X3 Tab;
-      double msum, max_d;
-      D3 v0;
-      int e = lane;
-      const bool obst_round = HAS_OBST && round == 0;
-      if (obst_round) {
-        have = active && finite;
-        sa = hull_desc(L);
-        sb = cyl_desc();
-        Tab = Trel;
-        msum = M_HULL + M_CYL;
-        max_d = msum + 0.02 + 5.0;  // get_link_distances queries with distance=5.0 (pyb_setup.py:452)
-        v0 = v0_obst;
+      if (round == 0) {
+        have = s_env[lane] >= 0 && (HAS_OBST || (cfg.check_collision && MODE != MODE_RESET));
+        item = (uint32_t)lane | (3u << 6) | ((uint32_t)(wv + 2) << 8);
       } else {
-        const int it = (round - first_q) * THREADS + tid;
-        have = it < qn;
-        const uint32_t item = have ? s_queue[it] : 0u;
-        e = item & 63;
-        const int kind = (item >> 6) & 3, lb = (item >> 8) & 7, la = (item >> 11) & 7;
+        const int it = (round - 1) * THREADS + tid;
+        have = it < s_qcount;
+        item = have ? s_queue[it] : 0u;
+      }
+      const int e = item & 63, kind = (item >> 6) & 3, lb = (item >> 8) & 7, la = (item >> 11) & 7;
+      ShapeDesc sa = hull_desc(1), sb = cyl_desc();
+      X3 Tab = identity_x3();
+      D3 v0 = d3(0, 1, 0);
+      bool run = false;
+      if (have) {
         X3 T = identity_x3(), TA = identity_x3();
+        D3 capA0[3], capA1[3];
+#pragma unroll
         for (int k = 0; k < 6; k++) {
-          if (have && k < lb) {
+          if (k < lb) {
             fk_joint(T, k, s_q[k][e]);
             if (k + 1 == la) TA = T;
+            if (k < 3 && kind == 3) {
+              const double* c = c_tab.capsule[k];
+              capA0[k] = apply(T, d3(c[0], c[1], c[2]));
+              capA1[k] = apply(T, d3(c[3], c[4], c[5]));
+            }
           }
         }
-        if (kind == Q_SELF) {
-          sa = hull_desc(la < 1 ? 1 : la);
-          sb = hull_desc(lb < 1 ? 1 : lb);
-          Tab = rel(T, TA);
-          msum = M_HULL + M_HULL;
-          v0 = rotT(T, d3(0, 1, 0));
+        if (kind == 3) {
+          // obstacle item: first the conservative culling of the other pairs of this link
+          if (cfg.check_collision && MODE != MODE_RESET) {
+            const double* c = c_tab.capsule[lb - 1];
+            D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
+            const double rb = c[6];
+            const double lim = cfg.collision_margin + 1e-6;
+            if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim)
+              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TABLE << 6) | ((uint32_t)lb << 8);
+            if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim)
+              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TRACK << 6) | ((uint32_t)lb << 8);
+            // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6), filed under link B
+#pragma unroll
+            for (int A = 1; A <= 3; A++) {
+              if (A <= lb - 2) {
+                const double ra = c_tab.capsule[A - 1][6];
+                if (segseg_dist(capA0[A - 1], capA1[A - 1], b0, b1) - ra - rb <= lim)
+                  s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
+              }
+            }
+          }
+          if (HAS_OBST) {
+            X3 To;
+            quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
+            To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
+            sa = hull_desc(lb);
+            sb = cyl_desc();
+            Tab = rel(To, T);
+            v0 = rotT(To, d3(0, 1, 0));  // Bullet's pair detector starts from the world +Y axis
+            run = true;
+          }
         } else {
-          const bool tbl = (kind == Q_TABLE);
-          sa = hull_desc(lb < 1 ? 1 : lb);
-          sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
-          Tab = T;
-          Tab.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
-          msum = M_HULL + (tbl ? M_TABLE : M_TRACK);
-          v0 = d3(0, 1, 0);
+          if (kind == Q_SELF) {
+            sa = hull_desc(la);
+            sb = hull_desc(lb);
+            Tab = rel(T, TA);
+            v0 = rotT(T, d3(0, 1, 0));
+          } else {
+            const bool tbl = (kind == Q_TABLE);
+            sa = hull_desc(lb);
+            sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
+            Tab = T;
+            Tab.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+          }
+          run = true;
         }
-        max_d = msum + 0.02 + cfg.collision_margin;  // check_collision queries with distance=0.01 (pyb_setup.py:402-422)
       }
-      if (have) {
+      if (run) {
+        // Bullet margins of the pair and its early-out distance (margins + 0.02 + query threshold): get_link_distances
+        // queries with distance=5.0 (pyb_setup.py:452), check_collision with 0.01 (pyb_setup.py:402-422)
+        const double mB = (kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK));
+        const double thr = (kind == 3) ? 5.0 : cfg.collision_margin;
         int info;
-        const double core = gjk_core_distance(P.graph, sa, Tab, sb, v0, max_d, info);
-        if (obst_round) {
+        const double core = gjk_core_distance(P.graph, sa, Tab, sb, v0, (M_HULL + mB) + 0.02 + thr, info);
+        const double msum = M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
+        if (kind == 3) {
           double dist = core - msum;
-          if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[lane], URGYM_STATUS_PENETRATION); }
-          if (info & GJK_ITERCAP) atomicOr(&s_flags[lane], URGYM_STATUS_GJK_ITER);
-          s_dist[wv][lane] = dist;
+          if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION); }
+          if (info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+          s_dist[lb - 2][e] = dist;
         } else {
           const bool hit = (info & GJK_PENETRATING) || (!(info & GJK_SEPARATED) && (core - msum) <= cfg.collision_margin);
           if (hit) atomicOr(&s_coll[e], 1);
         }
-      } else if (obst_round) {
-        s_dist[wv][lane] = (active && !finite) ? __builtin_nan("") : 1e30;
+      } else if (round == 0 && HAS_OBST) {
+        s_dist[wv][lane] = (s_env[lane] <= -2) ? __builtin_nan("") : 1e30;
       }
     }
   }
   __syncthreads();
 
-  // ---- P4: wave 4 re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
-  if (wv == WAVES - 1 && active) {
+  // ---- P4: one lane per env re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
+  if (wv == WAVES - 1 && s_env[lane] != -1) {
+    const int n = s_env[lane] >= 0 ? s_env[lane] : -2 - s_env[lane];
     double q[6];
     for (int i = 0; i < 6; i++) q[i] = s_q[i][lane];
     X3 TE = identity_x3();
@@ -658,17 +636,50 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   } else {
     const int cnt = min(ENVS_PER_GROUP, list_count - (int)blockIdx.x * ENVS_PER_GROUP);
     for (int i = tid; i < cnt * OD; i += THREADS) {
-      int e = i / OD;
-      int ne = B.done_list[blockIdx.x * ENVS_PER_GROUP + e];
+      const int e = i / OD;
+      const int se = s_env[e];
+      const int ne = se >= 0 ? se : -2 - se;
       B.observation[(size_t)ne * OD + (i % OD)] = s_out[e * 47 + (i % OD)];
     }
     for (int i = tid; i < cnt * GD; i += THREADS) {
-      int e = i / GD;
-      int ne = B.done_list[blockIdx.x * ENVS_PER_GROUP + e];
+      const int e = i / GD;
+      const int se = s_env[e];
+      const int ne = se >= 0 ? se : -2 - se;
       B.achieved_goal[(size_t)ne * GD + (i % GD)] = s_out[e * 47 + OD + (i % GD)];
       B.desired_goal[(size_t)ne * GD + (i % GD)] = s_out[e * 47 + OD + GD + (i % GD)];
     }
   }
+}
+
+// unit probe: one closest-distance query per lane through the very same device GJK (tests only; not on the hot path)
+__global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, const double* par_a, const double* pose_a,
+                                     const int* type_b, const double* par_b, const double* pose_b, double threshold,
+                                     double* out_dist, int* out_info) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  auto mk = [](int type, const double* par, double& margin) {
+    ShapeDesc s;
+    s.type = type; s.hull = 0; s.hx = s.hy = s.hz = 0.0;
+    auto safe = [](double a, double b, double c) { double m = 0.1 * fmin(a, fmin(b, c)); return m < 0.04 ? m : 0.04; };
+    if (type == SH_HULL) { s.hull = (int)par[0] - 1; margin = M_HULL; }
+    else if (type == SH_CYLZ) { double m = safe(par[0], par[0], 0.5 * par[1]); s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; margin = m; }
+    else if (type == SH_BOX) { double m = safe(par[0], par[1], par[2]); s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; margin = m; }
+    else { margin = par[0]; }
+    return s;
+  };
+  double ma, mb;
+  ShapeDesc A = mk(type_a[i], par_a + 3 * i, ma), Bs = mk(type_b[i], par_b + 3 * i, mb);
+  X3 Ta, Tb;
+  const double* pa = pose_a + 7 * i;
+  const double* pb = pose_b + 7 * i;
+  quat_to_rot(Q4{pa[3], pa[4], pa[5], pa[6]}, Ta.r);
+  Ta.t = d3(pa[0], pa[1], pa[2]);
+  quat_to_rot(Q4{pb[3], pb[4], pb[5], pb[6]}, Tb.r);
+  Tb.t = d3(pb[0], pb[1], pb[2]);
+  int info;
+  const double core = gjk_core_distance(g, A, rel(Tb, Ta), Bs, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
+  out_dist[i] = (info & GJK_PENETRATING) ? -(ma + mb) : core - ma - mb;
+  out_info[i] = info;
 }
 
 // compaction of an explicit reset / refresh mask into done_list (mask == nullptr: every env)
@@ -692,9 +703,8 @@ struct Handle {
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
   double* d_verts64 = nullptr;
-  int* d_adj_off = nullptr;
-  unsigned short* d_adj_idx = nullptr;
-  unsigned short* d_seeds = nullptr;
+  NbrRec* d_recs = nullptr;
+  SeedRec* d_seeds = nullptr;
   uint64_t seed = 0;
   int pp = 0;
   char err[512] = {0};
@@ -767,8 +777,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.cfg = h->cfg;
   P.buf = h->buf;
   P.graph.verts = h->d_verts64;
-  P.graph.adj_off = h->d_adj_off;
-  P.graph.adj_idx = h->d_adj_idx;
+  P.graph.recs = h->d_recs;
   P.graph.seeds = h->d_seeds;
   P.obs_dim = h->obs_dim;
   P.goal_dim = h->goal_dim;
@@ -885,7 +894,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   memcpy(t.joint_rot, UR5E_JOINT_ROT, sizeof(t.joint_rot));
   memcpy(t.joint_xyz, UR5E_JOINT_XYZ, sizeof(t.joint_xyz));
   memcpy(t.capsule, UR5E_CAPSULE, sizeof(t.capsule));
-  static_assert(UR5E_NUM_SEEDS == HULL_SEEDS, "seed table width");
+  HostTables tabs = build_host_tables();
   e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
   if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpyToSymbol(c_tab)", e); }
   auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
@@ -894,13 +903,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
-  if (e == hipSuccess) e = upload((void**)&h->d_adj_off, UR5E_ADJ_OFFSET, sizeof(UR5E_ADJ_OFFSET));
-  if (e == hipSuccess) e = upload((void**)&h->d_adj_idx, UR5E_ADJ_INDEX, sizeof(UR5E_ADJ_INDEX));
-  if (e == hipSuccess) e = upload((void**)&h->d_seeds, UR5E_SEEDS, sizeof(UR5E_SEEDS));
+  if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
+  if (e == hipSuccess) e = upload((void**)&h->d_seeds, tabs.seeds, sizeof(tabs.seeds));
   if (e != hipSuccess) {
     if (h->d_verts64) hipFree(h->d_verts64);
-    if (h->d_adj_off) hipFree(h->d_adj_off);
-    if (h->d_adj_idx) hipFree(h->d_adj_idx);
+    if (h->d_recs) hipFree(h->d_recs);
     if (h->d_seeds) hipFree(h->d_seeds);
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
@@ -915,8 +922,7 @@ int urgym_destroy(void* handle) {
   hipSetDevice(h->device);
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_verts64) hipFree(h->d_verts64);
-  if (h->d_adj_off) hipFree(h->d_adj_off);
-  if (h->d_adj_idx) hipFree(h->d_adj_idx);
+  if (h->d_recs) hipFree(h->d_recs);
   if (h->d_seeds) hipFree(h->d_seeds);
   delete h;
   return URGYM_OK;
@@ -973,6 +979,20 @@ int urgym_rollout(void* handle, const float* actions_dev, int num_steps, void* s
     rc = do_step(h, actions_dev + (size_t)k * h->cfg.num_envs * 6, (hipStream_t)stream);
     if (rc) return rc;
   }
+  return URGYM_OK;
+}
+
+int urgym_probe_closest(void* handle, int count, const int* type_a, const double* par_a, const double* pose_a, const int* type_b,
+                        const double* par_b, const double* pose_b, double threshold, double* out_dist, int* out_info, void* stream) {
+  Handle* h = (Handle*)handle;
+  if (!h || count < 0) return fail(h, URGYM_ERR_ARG, "urgym_probe_closest: bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (count == 0) return URGYM_OK;
+  HullGraph g;
+  g.verts = h->d_verts64; g.recs = h->d_recs; g.seeds = h->d_seeds;
+  hipLaunchKernelGGL(probe_closest_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, g, count, type_a, par_a, pose_a,
+                     type_b, par_b, pose_b, threshold, out_dist, out_info);
+  HIP_TRY(h, hipGetLastError());
   return URGYM_OK;
 }
 

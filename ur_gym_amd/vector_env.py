@@ -232,6 +232,23 @@ class UR5ReachVectorEnv:
             self._refresh(None)
         self._needs_reset = False
 
+    def probe_closest(self, type_a, par_a, pose_a, type_b, par_b, pose_b, threshold=5.0):
+        """Unit probe of the device closest-distance routine (urgym_probe_closest): arrays of queries -> (dist, info)."""
+        dev = self.device
+        ta = torch.as_tensor(np.asarray(type_a, np.int32), device=dev)
+        tb = torch.as_tensor(np.asarray(type_b, np.int32), device=dev)
+        n = ta.numel()
+        pa = torch.as_tensor(np.asarray(par_a, np.float64).reshape(n, 3), device=dev).contiguous()
+        pb = torch.as_tensor(np.asarray(par_b, np.float64).reshape(n, 3), device=dev).contiguous()
+        xa = torch.as_tensor(np.asarray(pose_a, np.float64).reshape(n, 7), device=dev).contiguous()
+        xb = torch.as_tensor(np.asarray(pose_b, np.float64).reshape(n, 7), device=dev).contiguous()
+        out = torch.zeros(n, dtype=torch.float64, device=dev)
+        info = torch.zeros(n, dtype=torch.int32, device=dev)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _native.check(self.lib.urgym_probe_closest(self._h, n, p(ta), p(pa), p(xa), p(tb), p(pb), p(xb), float(threshold), p(out), p(info),
+                                                  self._stream()), self._h)
+        return out.cpu().numpy(), info.cpu().numpy()
+
     # ------------------------------------------------------------------------------------------------ timing
     def enable_timing(self, on=True):
         _native.check(self.lib.urgym_enable_timing(self._h, int(on)), self._h)
