@@ -31,7 +31,10 @@ extern "C" int harness_closest(int type_a, const double* par_a, const double* po
   ShapeDesc A = desc(type_a, par_a, &ma), B = desc(type_b, par_b, &mb);
   X3 Ta = pose_to_x3(pose_a), Tb = pose_to_x3(pose_b);
   int info;
-  double core = gjk_core_distance(g, A, rel(Tb, Ta), B, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
+  double slot[GJK_SLOT_DOUBLES];
+  XRef Tr{slot, 1};
+  store(Tr, rel(Tb, Ta));
+  double core = gjk_core_distance(g, A, Tr, B, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
   out[0] = core - ma - mb;
   out[1] = info;
   return 0;

@@ -12,10 +12,12 @@
 #include <cmath>
 #define __device__
 #define __forceinline__ inline
+#define URGYM_LDS
 static inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 using std::fma; using std::sqrt; using std::fabs; using std::fmin; using std::fmax; using std::acos; using std::asin; using std::atan2;
 #else
 #include <hip/hip_runtime.h>
+#define URGYM_LDS __attribute__((address_space(3)))
 #endif
 
 namespace urgym {
@@ -58,6 +60,29 @@ __device__ __forceinline__ X3 rel(const X3& A, const X3& B) {
     for (int j = 0; j < 3; j++) C.r[i * 3 + j] = fma(A.r[i], B.r[j], fma(A.r[3 + i], B.r[3 + j], A.r[6 + i] * B.r[6 + j]));
   C.t = rotT(A, B.t - A.t);
   return C;
+}
+
+// A rigid transform parked in LDS (per-lane slot, element k at p[k * stride]: r[0..8] then t.xyz).  The GJK keeps its
+// pose operand there instead of in 24 VGPRs; it is re-read twice per iteration (18 + 12 ds_read_b64, conflict-free
+// because consecutive lanes own consecutive addresses).
+struct XRef {
+  URGYM_LDS double* p;
+  int stride;
+  __device__ __forceinline__ double at(int k) const { return p[k * stride]; }
+  __device__ __forceinline__ void set(int k, double v) const { p[k * stride] = v; }
+};
+__device__ __forceinline__ void store(XRef R, const X3& T) {
+#pragma unroll
+  for (int k = 0; k < 9; k++) R.set(k, T.r[k]);
+  R.set(9, T.t.x); R.set(10, T.t.y); R.set(11, T.t.z);
+}
+__device__ __forceinline__ D3 rotT(XRef T, D3 v) {
+  return d3(fma(T.at(0), v.x, fma(T.at(3), v.y, T.at(6) * v.z)), fma(T.at(1), v.x, fma(T.at(4), v.y, T.at(7) * v.z)),
+            fma(T.at(2), v.x, fma(T.at(5), v.y, T.at(8) * v.z)));
+}
+__device__ __forceinline__ D3 apply(XRef T, D3 v) {
+  return d3(fma(T.at(0), v.x, fma(T.at(1), v.y, T.at(2) * v.z)) + T.at(9), fma(T.at(3), v.x, fma(T.at(4), v.y, T.at(5) * v.z)) + T.at(10),
+            fma(T.at(6), v.x, fma(T.at(7), v.y, T.at(8) * v.z)) + T.at(11));
 }
 
 struct Q4 {
@@ -174,17 +199,23 @@ struct ShapeDesc {
 // climbing step is a single round trip of wide, independent loads (224 contiguous bytes) instead of the dependent
 // chain offset -> ids -> coordinates.  Vertices with more than 8 neighbours chain further records through `next`;
 // unused slots repeat the vertex itself (never "better", the comparison is strict).
-struct NbrRec {
-  int next;               // next record of the same vertex, -1 = none
+struct alignas(16) D2 {
+  double a, b;
+};
+struct alignas(16) U8 {
+  unsigned short v[8];
+};
+struct alignas(16) NbrRec {
+  int next;  // next record of the same vertex, -1 = none
   int pad[3];
-  unsigned short id[8];
-  double x[8], y[8], z[8];
+  U8 id;           // neighbour ids (global vertex ids)
+  D2 x[4], y[4], z[4];  // neighbour j: (x[j/2], y[j/2], z[j/2]).{a|b}
 };
 static_assert(sizeof(NbrRec) == 224, "record layout");
 constexpr int HULL_SEEDS = 16;
-struct SeedRec {          // well-spread start vertices of one hull
-  int id[HULL_SEEDS];
-  double x[HULL_SEEDS], y[HULL_SEEDS], z[HULL_SEEDS];
+struct alignas(16) SeedRec {  // well-spread start vertices of one hull, same packing (two blocks of 8)
+  U8 id[2];
+  D2 x[8], y[8], z[8];
 };
 struct HullGraph {
   const double* __restrict__ verts;   // [NV][3] exact link-frame vertices
@@ -196,10 +227,32 @@ struct HullGraph {
 // ranked identically on both sides.
 __device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) { return (x * d.x + y * d.y) + z * d.z; }
 
+// branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together)
+__device__ __forceinline__ void keep_better(double x, double y, double z, int id, D3 d, double& best, int& nxt, D3& pt) {
+  const double t = vdot3(x, y, z, d);
+  const bool g = t > best;
+  best = g ? t : best;
+  nxt = g ? id : nxt;
+  pt.x = g ? x : pt.x; pt.y = g ? y : pt.y; pt.z = g ? z : pt.z;
+}
+// four candidates packed as two D2 triples + their ids: the six 16-byte coordinate loads are issued before the first use
+// (eight at once would need 48 VGPRs for the coordinates alone and costs a wave per SIMD)
+__device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, const D2* xp, const D2* yp, const D2* zp, D3 d,
+                                             double& best, int& nxt, D3& pt) {
+  const D2 x0 = xp[0], x1 = xp[1];
+  const D2 y0 = yp[0], y1 = yp[1];
+  const D2 z0 = zp[0], z1 = zp[1];
+  keep_better(x0.a, y0.a, z0.a, i0, d, best, nxt, pt);
+  keep_better(x0.b, y0.b, z0.b, i1, d, best, nxt, pt);
+  keep_better(x1.a, y1.a, z1.a, i2, d, best, nxt, pt);
+  keep_better(x1.b, y1.b, z1.b, i3, d, best, nxt, pt);
+}
+
 // Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
 // On a convex polytope a vertex with no better neighbour is a global maximiser of the linear function, so this is
 // the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph) at ~16-32 dot
 // products instead of one per vertex.  `cur` carries the previous answer of this GJK run (warm start); -1 = none.
+// One climbing step = one round trip: the whole 224-byte record of the current vertex is fetched at once.
 __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d, int& cur) {
   double best;
   D3 pt;
@@ -207,11 +260,13 @@ __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d
     const SeedRec& S = g.seeds[h];
     best = -1.0e300;
     pt = d3(0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < HULL_SEEDS; s++) {
-      const double t = vdot3(S.x[s], S.y[s], S.z[s], d);
-      if (t > best) { best = t; cur = S.id[s]; pt = d3(S.x[s], S.y[s], S.z[s]); }
-    }
+    int c = 0;
+    const U8 ia = S.id[0], ib = S.id[1];
+    keep_best_of4(ia.v[0], ia.v[1], ia.v[2], ia.v[3], &S.x[0], &S.y[0], &S.z[0], d, best, c, pt);
+    keep_best_of4(ia.v[4], ia.v[5], ia.v[6], ia.v[7], &S.x[2], &S.y[2], &S.z[2], d, best, c, pt);
+    keep_best_of4(ib.v[0], ib.v[1], ib.v[2], ib.v[3], &S.x[4], &S.y[4], &S.z[4], d, best, c, pt);
+    keep_best_of4(ib.v[4], ib.v[5], ib.v[6], ib.v[7], &S.x[6], &S.y[6], &S.z[6], d, best, c, pt);
+    cur = c;
   } else {
     const double* p = g.verts + 3 * cur;
     pt = d3(p[0], p[1], p[2]);
@@ -222,12 +277,11 @@ __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d
     int rec = cur;
     do {
       const NbrRec& R = g.recs[rec];
-#pragma unroll
-      for (int j = 0; j < 8; j++) {
-        const double t = vdot3(R.x[j], R.y[j], R.z[j], d);
-        if (t > best) { best = t; nxt = R.id[j]; pt = d3(R.x[j], R.y[j], R.z[j]); }
-      }
-      rec = R.next;
+      const int nextrec = R.next;
+      const U8 id = R.id;  // header + ids travel with the first half's coordinates
+      keep_best_of4(id.v[0], id.v[1], id.v[2], id.v[3], &R.x[0], &R.y[0], &R.z[0], d, best, nxt, pt);
+      keep_best_of4(id.v[4], id.v[5], id.v[6], id.v[7], &R.x[2], &R.y[2], &R.z[2], d, best, nxt, pt);
+      rec = nextrec;
     } while (rec >= 0);
     if (nxt == cur) break;
     cur = nxt;
@@ -286,7 +340,19 @@ enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4 };
 //   max_d : Bullet's early-out distance (marginA + marginB + 0.02 + query threshold) on the core distance; when a
 //           separating axis proves the cores farther apart than that the search stops (GJK_SEPARATED).
 // Returns the core distance |v|; GJK_PENETRATING when the cores touch/overlap (Bullet would enter EPA).
-__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, const X3& T, const ShapeDesc& B,
+// Per-lane LDS slot of the GJK (element k at p[k * stride]):
+//   0..11  pose of A in B's frame (row-major 3x3, then translation)
+//   12..23 the simplex vertices w[0..3] (Minkowski-difference points)
+// Keeping these 24 doubles out of the register file is what lets the float64 GJK run without scratch spills; the
+// simplex is indexed dynamically (w[n] = ...) exactly like Bullet's arrays.
+// (Bullet's inSimplex also tests w == m_lastW.  That test can never fire on its own: the vertex added last is still in
+// the simplex unless the reduction dropped it, and then the closest point did not move, so the no-progress exit has
+// already ended the loop in that same iteration.  m_lastW is therefore not stored.)
+constexpr int GJK_SLOT_DOUBLES = 24;
+__device__ __forceinline__ D3 ldw(XRef T, int i) { return d3(T.at(12 + 3 * i), T.at(13 + 3 * i), T.at(14 + 3 * i)); }
+__device__ __forceinline__ void stw(XRef T, int i, D3 w) { T.set(12 + 3 * i, w.x); T.set(13 + 3 * i, w.y); T.set(14 + 3 * i, w.z); }
+
+__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
                                                     D3 v0, double max_d, int& info) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
@@ -294,28 +360,28 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
   D3 v = v0;
   double sq = 1.0e300;
   const double max_d2 = max_d * max_d;
-  D3 s0 = d3(0, 0, 0), s1 = s0, s2 = s0, s3 = s0;
-  D3 last_w = d3(1e300, 1e300, 1e300);
   int n = 0;
   bool check_simplex = false;
   int degenerate = 0;
   int iter = 0;
   int curA = -1, curB = -1;  // warm starts of the two hull searches
   for (;;) {
-    D3 p = apply(T, support_local(g, A, rotT(T, -v), curA));
-    D3 q = support_local(g, B, v, curB);
-    D3 w = p - q;
+    D3 w;
+    {
+      D3 p = apply(T, support_local(g, A, rotT(T, -v), curA));
+      D3 q = support_local(g, B, v, curB);
+      w = p - q;
+    }
     double delta = dot(v, w);
     if (delta > 0.0 && delta * delta > sq * max_d2) { degenerate = 10; check_simplex = true; break; }
     {
-      bool in = (n > 0 && len2(s0 - w) <= 1e-12) || (n > 1 && len2(s1 - w) <= 1e-12) || (n > 2 && len2(s2 - w) <= 1e-12) ||
-                (n > 3 && len2(s3 - w) <= 1e-12) || (w.x == last_w.x && w.y == last_w.y && w.z == last_w.z);
+      bool in = false;
+      for (int i = 0; i < n; i++) in = in || (len2(ldw(T, i) - w) <= 1e-12);
       if (in) { degenerate = 1; check_simplex = true; break; }
     }
     double f0 = sq - delta, f1 = sq * REL_ERROR2;
     if (f0 <= f1) { degenerate = (f0 <= 0.0) ? 2 : 11; check_simplex = true; break; }
-    last_w = w;
-    if (n == 0) s0 = w; else if (n == 1) s1 = w; else if (n == 2) s2 = w; else s3 = w;
+    stw(T, n, w);
     n++;
     // ---- closest point of the simplex to the origin + vertex reduction
     D3 nv = d3(0, 0, 0);
@@ -323,10 +389,11 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
     bool ua = true, ub = true, uc = true, ud = true;
     bool reduce = true;
     if (n == 1) {
-      nv = s0;
+      nv = w;
       reduce = false;
     } else if (n == 2) {
-      D3 e = s1 - s0;
+      D3 s0 = ldw(T, 0);
+      D3 e = w - s0;
       double t = -dot(e, s0);
       if (t > 0.0) {
         double ee = dot(e, e);
@@ -340,7 +407,7 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
       uc = ud = false;
     } else if (n == 3) {
       int m;
-      nv = tri_closest(s0, s1, s2, m);
+      nv = tri_closest(ldw(T, 0), ldw(T, 1), w, m);
       ua = m & 1; ub = m & 2; uc = m & 4; ud = false;
     } else {
       // faces in Bullet's order: ABC|D, ACD|B, ADB|C, BDC|A
@@ -349,12 +416,11 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
       ua = ub = uc = ud = false;
 #pragma unroll 1
       for (int f = 0; f < 4; f++) {
-        D3 a = (f == 3) ? s1 : s0;
-        D3 b = (f == 0) ? s1 : ((f == 1) ? s2 : s3);
-        D3 c = (f == 0) ? s2 : ((f == 1) ? s3 : ((f == 2) ? s1 : s2));
-        D3 o = (f == 0) ? s3 : ((f == 1) ? s1 : ((f == 2) ? s2 : s0));
+        const int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
+        const int io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
+        D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
         D3 nrm = cross(b - a, c - a);
-        double signp = -dot(a, nrm), signd = dot(o - a, nrm);
+        double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
         if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
         else if (signp * signd < 0.0) {
           int m3;
@@ -363,11 +429,8 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
           if (!any_out || l < best) {
             best = l;
             nv = pt;
-            const bool ma = m3 & 1, mb = m3 & 2, mc = m3 & 4;
-            ua = (f == 3) ? false : ma;
-            ub = (f == 0) ? mb : ((f == 2) ? mc : ((f == 3) ? ma : false));
-            uc = (f == 0) ? mc : ((f == 1) ? mb : ((f == 3) ? mc : false));
-            ud = (f == 0) ? false : ((f == 1) ? mc : mb);
+            const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+            ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
           }
           any_out = true;
         }
@@ -383,9 +446,9 @@ __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const Sh
     if (reduce) {
       // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
       if (n >= 4 && !ud) { n--; }
-      if (n >= 3 && !uc) { n--; D3 l = (n == 2) ? s2 : s3; s2 = l; }
-      if (n >= 2 && !ub) { n--; D3 l = (n == 1) ? s1 : ((n == 2) ? s2 : s3); s1 = l; }
-      if (n >= 1 && !ua) { n--; D3 l = (n == 0) ? s0 : ((n == 1) ? s1 : ((n == 2) ? s2 : s3)); s0 = l; }
+      if (n >= 3 && !uc) { n--; stw(T, 2, ldw(T, n)); }
+      if (n >= 2 && !ub) { n--; stw(T, 1, ldw(T, n)); }
+      if (n >= 1 && !ua) { n--; stw(T, 0, ldw(T, n)); }
     }
     if (!valid) { degenerate = 3; check_simplex = true; break; }
     double nsq = len2(nv);

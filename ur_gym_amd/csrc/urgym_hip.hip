@@ -93,12 +93,10 @@ __device__ __forceinline__ ShapeDesc point_desc() {
 }
 
 // one joint of the URDF chain: T <- T * [R_fix | xyz] * Rz(q)   (ur5e.urdf:232-279)
-__device__ __forceinline__ void fk_joint(X3& T, int k, double qk) {
+__device__ __forceinline__ void fk_joint(X3& T, int k, double s, double c) {  // s, c = sin / cos of joint k
   const double* F = c_tab.joint_rot[k];
   const double* o = c_tab.joint_xyz[k];
   T.t = T.t + rot(T, d3(o[0], o[1], o[2]));
-  double s, c;
-  sincos(qk, &s, &c);
   // G = F * Rz(q): columns 0,1 mix, column 2 unchanged
   double g[9];
 #pragma unroll
@@ -194,7 +192,7 @@ __device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const d
 
 // ---- RESET: one lane samples a new episode (reach.py:197-200, 313-326, 664-683; samplers utils.py:81-100)
 template <int KIND>
-__device__ void sample_episode(const KParams& P, int n, int& flags) {
+__device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
   const int N = cfg.num_envs;
@@ -253,7 +251,8 @@ __device__ void sample_episode(const KParams& P, int n, int& flags) {
       Tt.t = d3(goal[0], goal[1], goal[2]);
       int info;
       // Bullet's pair detector starts from the world +Y axis; B's frame is the obstacle's
-      double core = gjk_core_distance(P.graph, ta, rel(To, Tt), cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
+      store(slot, rel(To, Tt));
+      double core = gjk_core_distance(P.graph, ta, slot, cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
       double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
       fail = dist < cfg.target_clearance;
     }
@@ -272,16 +271,16 @@ __device__ void sample_episode(const KParams& P, int n, int& flags) {
 }
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const float* __restrict__ actions) {
-  __shared__ float s_out[ENVS_PER_GROUP * 47];  // observation | achieved | desired rows staged for coalesced stores
+__global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const float* __restrict__ actions) {
   __shared__ double s_dist[WAVES][ENVS_PER_GROUP];
-  __shared__ double s_q[6][ENVS_PER_GROUP];     // joint vector of the step (after the action)
+  __shared__ double s_sc[12][ENVS_PER_GROUP];   // sin (0..5) and cos (6..11) of those joints: computed once, used by every FK
   __shared__ double s_obst[7][ENVS_PER_GROUP];  // obstacle position + quaternion of the step (after its motion)
   __shared__ uint32_t s_queue[QUEUE_CAP];
   __shared__ int s_qcount;
   __shared__ int s_coll[ENVS_PER_GROUP];
   __shared__ int s_flags[ENVS_PER_GROUP];
   __shared__ int s_env[ENVS_PER_GROUP];         // global env id of slot e, -1 = empty slot
+  __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];        // per-lane GJK operand: pose of shape A in B's frame (+ Bullet's m_lastW)
 
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
@@ -291,6 +290,9 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int OD = P.obs_dim, GD = P.goal_dim;
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
+  const XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
+  float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
+  static_assert(sizeof(float) * ENVS_PER_GROUP * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
 
   int list_count = 0;
   if (MODE != MODE_STEP) {
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
     if (MODE == MODE_STEP) n = idx < N ? idx : -1;
     else n = idx < list_count ? B.done_list[idx] : -1;
     int flags = 0;
-    if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, n, flags);  // writes goal / obstacle / q / episode_id
+    if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
     s_flags[lane] = flags;
     s_coll[lane] = 0;
     if (lane == 0) s_qcount = 0;
@@ -342,7 +344,12 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       }
     }
     s_env[lane] = (n >= 0 && finite) ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
-    for (int i = 0; i < 6; i++) s_q[i][lane] = q[i];
+    for (int i = 0; i < 6; i++) {
+      double sn, cs;
+      sincos(q[i], &sn, &cs);
+      s_sc[i][lane] = sn;
+      s_sc[6 + i][lane] = cs;
+    }
     s_obst[0][lane] = opos[0]; s_obst[1][lane] = opos[1]; s_obst[2][lane] = opos[2];
     s_obst[3][lane] = oq.x; s_obst[4][lane] = oq.y; s_obst[5][lane] = oq.z; s_obst[6][lane] = oq.w;
   }
@@ -370,22 +377,21 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
       }
       const int e = item & 63, kind = (item >> 6) & 3, lb = (item >> 8) & 7, la = (item >> 11) & 7;
       ShapeDesc sa = hull_desc(1), sb = cyl_desc();
-      X3 Tab = identity_x3();
       D3 v0 = d3(0, 1, 0);
       bool run = false;
       if (have) {
         X3 T = identity_x3(), TA = identity_x3();
-        D3 capA0[3], capA1[3];
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-          if (k < lb) {
-            fk_joint(T, k, s_q[k][e]);
-            if (k + 1 == la) TA = T;
-            if (k < 3 && kind == 3) {
-              const double* c = c_tab.capsule[k];
-              capA0[k] = apply(T, d3(c[0], c[1], c[2]));
-              capA1[k] = apply(T, d3(c[3], c[4], c[5]));
-            }
+        // FK to link lb; the world capsules of links 1..3 (self-collision culling) are parked in the lane's LDS slot,
+        // which is free until the GJK operand is stored
+#pragma unroll 1
+        for (int k = 0; k < lb; k++) {
+          fk_joint(T, k, s_sc[k][e], s_sc[6 + k][e]);
+          if (k + 1 == la) TA = T;
+          if (k < 3 && kind == 3) {
+            const double* c = c_tab.capsule[k];
+            const D3 c0 = apply(T, d3(c[0], c[1], c[2])), c1 = apply(T, d3(c[3], c[4], c[5]));
+            pose_slot.set(6 * k + 0, c0.x); pose_slot.set(6 * k + 1, c0.y); pose_slot.set(6 * k + 2, c0.z);
+            pose_slot.set(6 * k + 3, c1.x); pose_slot.set(6 * k + 4, c1.y); pose_slot.set(6 * k + 5, c1.z);
           }
         }
         if (kind == 3) {
@@ -400,13 +406,14 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
             if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim)
               s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TRACK << 6) | ((uint32_t)lb << 8);
             // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6), filed under link B
-#pragma unroll
-            for (int A = 1; A <= 3; A++) {
-              if (A <= lb - 2) {
-                const double ra = c_tab.capsule[A - 1][6];
-                if (segseg_dist(capA0[A - 1], capA1[A - 1], b0, b1) - ra - rb <= lim)
-                  s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
-              }
+#pragma unroll 1
+            for (int A = 1; A <= 3 && A <= lb - 2; A++) {
+              const double ra = c_tab.capsule[A - 1][6];
+              const int o = 6 * (A - 1);
+              const D3 a0 = d3(pose_slot.at(o), pose_slot.at(o + 1), pose_slot.at(o + 2));
+              const D3 a1 = d3(pose_slot.at(o + 3), pose_slot.at(o + 4), pose_slot.at(o + 5));
+              if (segseg_dist(a0, a1, b0, b1) - ra - rb <= lim)
+                s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
             }
           }
           if (HAS_OBST) {
@@ -415,7 +422,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
             To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
             sa = hull_desc(lb);
             sb = cyl_desc();
-            Tab = rel(To, T);
+            store(pose_slot, rel(To, T));
             v0 = rotT(To, d3(0, 1, 0));  // Bullet's pair detector starts from the world +Y axis
             run = true;
           }
@@ -423,14 +430,14 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
           if (kind == Q_SELF) {
             sa = hull_desc(la);
             sb = hull_desc(lb);
-            Tab = rel(T, TA);
+            store(pose_slot, rel(T, TA));
             v0 = rotT(T, d3(0, 1, 0));
           } else {
             const bool tbl = (kind == Q_TABLE);
             sa = hull_desc(lb);
             sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
-            Tab = T;
-            Tab.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+            T.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+            store(pose_slot, T);
           }
           run = true;
         }
@@ -441,7 +448,7 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
         const double mB = (kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK));
         const double thr = (kind == 3) ? 5.0 : cfg.collision_margin;
         int info;
-        const double core = gjk_core_distance(P.graph, sa, Tab, sb, v0, (M_HULL + mB) + 0.02 + thr, info);
+        const double core = gjk_core_distance(P.graph, sa, pose_slot, sb, v0, (M_HULL + mB) + 0.02 + thr, info);
         const double msum = M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
         if (kind == 3) {
           double dist = core - msum;
@@ -462,11 +469,19 @@ __global__ void __launch_bounds__(THREADS, 4) env_kernel(const KParams P, const 
   // ---- P4: one lane per env re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
   if (wv == WAVES - 1 && s_env[lane] != -1) {
     const int n = s_env[lane] >= 0 ? s_env[lane] : -2 - s_env[lane];
+    // the joint vector again, by the very arithmetic of P1 (cheaper than 3 KB of LDS)
     double q[6];
-    for (int i = 0; i < 6; i++) q[i] = s_q[i][lane];
+    for (int i = 0; i < 6; i++) {
+      q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
+      if (MODE == MODE_STEP) {
+        float a = actions[(size_t)n * 6 + i];
+        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+        q[i] += (double)__fmul_rn(__fmul_rn(a, 3.14159274101257324f), 0.1f);
+      }
+    }
     X3 TE = identity_x3();
-#pragma unroll
-    for (int k = 0; k < 6; k++) fk_joint(TE, k, q[k]);
+#pragma unroll 1
+    for (int k = 0; k < 6; k++) fk_joint(TE, k, s_sc[k][lane], s_sc[6 + k][lane]);
     double opos[3] = {s_obst[0][lane], s_obst[1][lane], s_obst[2][lane]};
     Q4 oq{s_obst[3][lane], s_obst[4][lane], s_obst[5][lane], s_obst[6][lane]};
     const int step_count = B.step_count[n];
@@ -676,8 +691,11 @@ __global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, 
   Ta.t = d3(pa[0], pa[1], pa[2]);
   quat_to_rot(Q4{pb[3], pb[4], pb[5], pb[6]}, Tb.r);
   Tb.t = d3(pb[0], pb[1], pb[2]);
+  __shared__ double s_pose[GJK_SLOT_DOUBLES][64];
+  const XRef slot{(URGYM_LDS double*)&s_pose[0][0] + threadIdx.x, 64};
+  store(slot, rel(Tb, Ta));
   int info;
-  const double core = gjk_core_distance(g, A, rel(Tb, Ta), Bs, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
+  const double core = gjk_core_distance(g, A, slot, Bs, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
   out_dist[i] = (info & GJK_PENETRATING) ? -(ma + mb) : core - ma - mb;
   out_info[i] = info;
 }

@@ -18,13 +18,15 @@ inline HostTables build_host_tables() {
   HostTables t;
   const int NV = UR5E_NUM_HULL_VERTS;
   t.recs.resize(NV);
+  auto set_slot = [&](NbrRec& r, int j, int v) {
+    r.id.v[j] = (unsigned short)v;
+    double* xs = &r.x[0].a; double* ys = &r.y[0].a; double* zs = &r.z[0].a;
+    xs[j] = UR5E_HULL_VERTS[v][0]; ys[j] = UR5E_HULL_VERTS[v][1]; zs[j] = UR5E_HULL_VERTS[v][2];
+  };
   auto fill = [&](NbrRec& r, int self) {
     r.next = -1;
     r.pad[0] = r.pad[1] = r.pad[2] = 0;
-    for (int j = 0; j < 8; j++) {
-      r.id[j] = (unsigned short)self;
-      r.x[j] = UR5E_HULL_VERTS[self][0]; r.y[j] = UR5E_HULL_VERTS[self][1]; r.z[j] = UR5E_HULL_VERTS[self][2];
-    }
+    for (int j = 0; j < 8; j++) set_slot(r, j, self);
   };
   for (int i = 0; i < NV; i++) fill(t.recs[i], i);
   for (int i = 0; i < NV; i++) {
@@ -39,17 +41,16 @@ inline HostTables build_host_tables() {
         slot = 0;
       }
       const int nb = UR5E_ADJ_INDEX[e];
-      NbrRec& r = t.recs[rec];
-      r.id[slot] = (unsigned short)nb;
-      r.x[slot] = UR5E_HULL_VERTS[nb][0]; r.y[slot] = UR5E_HULL_VERTS[nb][1]; r.z[slot] = UR5E_HULL_VERTS[nb][2];
+      set_slot(t.recs[rec], slot, nb);
       slot++;
     }
   }
   for (int h = 0; h < 6; h++)
     for (int s = 0; s < HULL_SEEDS; s++) {
       const int v = UR5E_SEEDS[h][s];
-      t.seeds[h].id[s] = v;
-      t.seeds[h].x[s] = UR5E_HULL_VERTS[v][0]; t.seeds[h].y[s] = UR5E_HULL_VERTS[v][1]; t.seeds[h].z[s] = UR5E_HULL_VERTS[v][2];
+      SeedRec& S = t.seeds[h];
+      S.id[s / 8].v[s % 8] = (unsigned short)v;
+      (&S.x[0].a)[s] = UR5E_HULL_VERTS[v][0]; (&S.y[0].a)[s] = UR5E_HULL_VERTS[v][1]; (&S.z[0].a)[s] = UR5E_HULL_VERTS[v][2];
     }
   return t;
 }
