@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Export the deterministic actor (latent_pi + mu) of the reference's shipped SAC checkpoints as plain float32 arrays.
+
+    python tests/golden/gen_actor_fixtures.py [--reference /root/reference]
+
+Source: Trained_Models/Trained_{Ori,Obs,Dyn}/best_model.zip -> policy.pth, loaded with torch.load(weights_only=True)
+(nothing from the file is executed).  These are DATA files of the reference (SB3 MultiInputPolicy weights); the GPU box
+has no /root/reference, so the closed-loop tests read these fixtures instead.  Also records the aggregate closed-loop
+results the reference ships next to each checkpoint (best.txt / best_modeltest_result.txt, first two lines).
+"""
+import argparse
+import io
+import json
+import os
+import re
+import zipfile
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    args = ap.parse_args()
+    out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "actors")
+    os.makedirs(out_dir, exist_ok=True)
+    summary = {}
+    for name, result_file in (("Ori", "best.txt"), ("Obs", "best.txt"), ("Dyn", "best_modeltest_result.txt")):
+        d = os.path.join(args.reference, "Trained_Models", f"Trained_{name}")
+        z = zipfile.ZipFile(os.path.join(d, "best_model.zip"))
+        sd = torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True, map_location="cpu")
+        arrs = {k.replace("actor.", "").replace(".", "_"): v.numpy().astype(np.float32)
+                for k, v in sd.items() if k.startswith("actor.latent_pi") or k.startswith("actor.mu")}
+        np.savez_compressed(os.path.join(out_dir, f"actor_{name.lower()}.npz"), **arrs)
+        lines = open(os.path.join(d, result_file)).read().splitlines()
+        rate = float(re.search(r"([\d.]+)%", lines[0]).group(1))
+        reward = float(re.search(r"(-?[\d.]+)\s*$", lines[1]).group(1))
+        rows = [l.split(",") for l in lines[2:] if l.strip()]
+        steps = np.array([float(r[2]) for r in rows])
+        summary[name.lower()] = {"success_rate_percent": rate, "mean_episode_reward": reward, "trials": len(rows),
+                                 "mean_last_step_index": float(steps.mean()), "in_features": int(arrs["latent_pi_0_weight"].shape[1])}
+        print(name, {k: v.shape for k, v in arrs.items()}, summary[name.lower()])
+    with open(os.path.join(out_dir, "reference_results.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
