@@ -29,6 +29,19 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418}
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command
+
+
+def measured_traffic(env_id, n):
+    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE corrected x2 as the
+    gfx950 guide prescribes + WRITE_SIZE); only valid for the configuration that was profiled (Dyn, N=65536)."""
+    if env_id != "UR5DynReach-v1" or n != 65536 or not os.path.exists(PMC_SUMMARY):
+        return None
+    try:
+        k = json.load(open(PMC_SUMMARY))["env_kernel<2, 0>"]
+        return float(k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(env_id, seed, budget_s=12.0):
@@ -155,7 +168,9 @@ def main():
             "config": {"workload": f"{args.env} N={n} per GPU, random actions U(-1,1), auto-reset, seed {args.seed}",
                        "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.env, n),
+                         "traffic_source": "profiles/r1/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
+                         "algorithmic_bytes_per_launch": algo,
                          "kernel": "env_kernel<Dyn,STEP>" if args.env == "UR5DynReach-v1" else "env_kernel<STEP>",
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
