@@ -33,6 +33,7 @@ enum {
   URGYM_ENV_ORI = 0, /* UR5OriReach-v1 : ReachOri, reach.py:141-236 */
   URGYM_ENV_OBS = 1, /* UR5ObsReach-v1 : ReachObs, reach.py:239-374 */
   URGYM_ENV_DYN = 2, /* UR5DynReach-v1 : ReachDyn, reach.py:576-785 */
+  URGYM_ENV_STA = 3, /* UR5StaReach-v1 : ReachSta, reach.py:377-573 (static obstacle; moves only when obst_end != 0) */
 };
 
 /* error codes */
@@ -87,7 +88,7 @@ typedef struct urgym_buffers {
   double* q;          /* [6][N] joint angles (pybullet joint state, UR5.py:346-351) */
   double* goal;       /* [6][N] goal xyz + rpy (Obs uses rows 0..2) */
   double* obst_start; /* [6][N] obstacle start xyz+rpy  (Obs: the static obstacle; reach.py:263,582) */
-  double* obst_end;   /* [6][N] obstacle end xyz+rpy    (Dyn only) */
+  double* obst_end;   /* [6][N] obstacle end xyz+rpy    (Dyn; Sta: all-zero = static obstacle, reach.py:306) */
   double* obst_pos;   /* [3][N] current obstacle position (Bullet base position) */
   double* obst_quat;  /* [4][N] current obstacle orientation xyzw */
   double* obst_vel;   /* [6][N] per-episode (v, omega) applied while step_count < dyn_motion_steps */
@@ -119,7 +120,7 @@ int urgym_abi_version(void);
 /* Fill cfg with the reference's constants for env_kind (reach.py constructors). */
 int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg);
 
-/* Observation layout: obs_dim = 18|26|35, goal_dim = 6|3|6 (core.py:241-247; reach.py:189,307,653). */
+/* Observation layout: obs_dim = 18|26|35|29, goal_dim = 6|3|6|6 (core.py:241-247; reach.py:189,307,653,453-457). */
 int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
 
 /* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device`. */

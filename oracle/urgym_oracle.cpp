@@ -742,12 +742,13 @@ void write_obs(const Oracle& o, int n, const X3 link[7], float* obs_row, float* 
     for (int i = 0; i < 5; i++) *p++ = (float)S(b.link_dist, i, n, N);
   } else {
     for (int i = 0; i < 6; i++) *p++ = (float)S(b.goal, i, n, N);
-    for (int i = 0; i < 3; i++) *p++ = (float)S(b.obst_pos, i, n, N);  // reach.py:654-655 read back from Bullet
+    for (int i = 0; i < 3; i++) *p++ = (float)S(b.obst_pos, i, n, N);  // reach.py:454-455 / 654-655 read back from Bullet
     Quat q{S(b.obst_quat, 0, n, N), S(b.obst_quat, 1, n, N), S(b.obst_quat, 2, n, N), S(b.obst_quat, 3, n, N)};
     double orpy[3];
     euler_from_quat_bullet(q, orpy);
     for (int i = 0; i < 3; i++) *p++ = (float)orpy[i];
-    for (int i = 0; i < 6; i++) *p++ = (float)vel_obs[i];
+    if (o.cfg.env_kind == URGYM_ENV_DYN)  // ReachSta.get_obs has no velocity slot (reach.py:457)
+      for (int i = 0; i < 6; i++) *p++ = (float)vel_obs[i];
     for (int i = 0; i < 5; i++) *p++ = (float)S(b.link_dist, i, n, N);
   }
   for (int i = 0; i < o.goal_dim; i++) {
@@ -795,7 +796,13 @@ void reset_env(Oracle& o, int n) {
     for (int i = 0; i < 3; i++) start[i] = c.obst_low[i] + (c.obst_high[i] - c.obst_low[i]) * d.u[5 + i];
     sample_euler_obstacle(d.u[8], d.u[9], d.u[10], start + 3);
     bool fail;
-    if (c.env_kind == URGYM_ENV_OBS) {
+    if (c.env_kind == URGYM_ENV_STA) {
+      // reach.py:467-472: target box half 0.025 (reach.py:416-424) at the goal pose vs the obstacle at its sampled pose
+      X3 tp{quat_to_mat(quat_from_euler_bullet(goal[3], goal[4], goal[5])), v3(goal[0], goal[1], goal[2])};
+      X3 op{quat_to_mat(quat_from_euler_bullet(start[3], start[4], start[5])), v3(start[0], start[1], start[2])};
+      GjkResult r = gjk_distance(make_box(0.025, 0.025, 0.025, tp), scene_obstacle(op), 5.0);
+      fail = r.distance < c.target_clearance;
+    } else if (c.env_kind == URGYM_ENV_OBS) {
       // reach.py:316-322: sphere target r=0.02 (reach.py:270-277) vs obstacle
       X3 op{quat_to_mat(quat_from_euler_bullet(start[3], start[4], start[5])), v3(start[0], start[1], start[2])};
       GjkResult r = gjk_distance(make_sphere(0.02, pose_at(goal[0], goal[1], goal[2])), scene_obstacle(op), 5.0);
@@ -821,7 +828,7 @@ void reset_env(Oracle& o, int n) {
   if (c.env_kind != URGYM_ENV_ORI) {
     for (int i = 0; i < 6; i++) {
       S(b.obst_start, i, n, N) = start[i];
-      S(b.obst_end, i, n, N) = end[i];
+      S(b.obst_end, i, n, N) = end[i];  // Sta: zeros = static obstacle (ReachSta.__init__, reach.py:406)
     }
     set_obstacle_pose(b, n, N, start);  // reach.py:319 / 678
     double vel[6] = {0, 0, 0, 0, 0, 0};
@@ -919,6 +926,17 @@ void step_env(Oracle& o, int n, const float* action) {
     }
     // 3. sim.step (core.py:309): obstacle base integrates the velocity just set
     integrate_obstacle(b, n, N, vel_obs, 20, c.dt / 20.0);
+  } else if (c.env_kind == URGYM_ENV_STA) {
+    // core.py:307-308: set_velocity only when obstacle_end is not all-zero; ReachSta.set_velocity (reach.py:518-541):
+    // full start->end twist (time_duration = 1) while the obstacle is farther than 0.05 from its end position
+    double start[6], end[6];
+    bool moving = false;
+    for (int i = 0; i < 6; i++) { start[i] = S(b.obst_start, i, n, N); end[i] = S(b.obst_end, i, n, N); moving = moving || end[i] != 0.0; }
+    if (moving) {
+      double dx = end[0] - S(b.obst_pos, 0, n, N), dy = end[1] - S(b.obst_pos, 1, n, N), dz = end[2] - S(b.obst_pos, 2, n, N);
+      if (std::sqrt(dx * dx + dy * dy + dz * dz) > 0.05) dyn_velocity(start, end, 1.0, vel_obs);
+      integrate_obstacle(b, n, N, vel_obs, 20, c.dt / 20.0);
+    }
   }
   b.step_count[n] = step_num + 1;
   X3 link[7];
@@ -1012,7 +1030,7 @@ void parallel_for(int N, int threads, F f) {
 extern "C" {
 
 int urgym_oracle_config_default(int env_kind, int num_envs, urgym_config* c) {
-  if (!c || env_kind < 0 || env_kind > 2 || num_envs <= 0) return URGYM_ERR_ARG;
+  if (!c || env_kind < 0 || env_kind > 3 || num_envs <= 0) return URGYM_ERR_ARG;
   std::memset(c, 0, sizeof(*c));
   c->env_kind = env_kind;
   c->num_envs = num_envs;
@@ -1046,7 +1064,12 @@ int urgym_oracle_config_default(int env_kind, int num_envs, urgym_config* c) {
   } else {
     c->w_distance = -70; c->w_orientation = -30;
     const double gl[3] = {0.4, -0.5, 0.0}, gh[3] = {0.75, 0.5, 0.2}, ol[3] = {0.5, -0.8, 0.25}, oh[3] = {1.2, 0.8, 0.75};
-    for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; c->obst_low[i] = ol[i]; c->obst_high[i] = oh[i]; }
+    const double sgl[3] = {0.3, -0.5, 0.0}, sgh[3] = {0.75, 0.5, 0.2}, sol[3] = {0.5, -0.5, 0.25}, soh[3] = {1.0, 0.5, 0.55};  // reach.py:385-388
+    const bool sta = env_kind == URGYM_ENV_STA;
+    for (int i = 0; i < 3; i++) {
+      c->goal_low[i] = sta ? sgl[i] : gl[i]; c->goal_high[i] = sta ? sgh[i] : gh[i];
+      c->obst_low[i] = sta ? sol[i] : ol[i]; c->obst_high[i] = sta ? soh[i] : oh[i];
+    }
     const double lw[5] = {8, 2.4, 1.2, 1.2, 0.2};
     double sum = 0;
     for (int i = 0; i < 5; i++) sum += lw[i];
@@ -1059,7 +1082,7 @@ int urgym_oracle_create(const urgym_config* cfg, void** handle) {
   if (!cfg || !handle) return URGYM_ERR_ARG;
   Oracle* o = new Oracle();
   o->cfg = *cfg;
-  o->obs_dim = cfg->env_kind == URGYM_ENV_ORI ? 18 : (cfg->env_kind == URGYM_ENV_OBS ? 26 : 35);
+  o->obs_dim = cfg->env_kind == URGYM_ENV_ORI ? 18 : (cfg->env_kind == URGYM_ENV_OBS ? 26 : (cfg->env_kind == URGYM_ENV_STA ? 29 : 35));
   o->goal_dim = cfg->env_kind == URGYM_ENV_OBS ? 3 : 6;
   std::memset(&o->buf, 0, sizeof(o->buf));
   *handle = o;

@@ -3,7 +3,7 @@
 
     python tests/golden/gen_actor_fixtures.py [--reference /root/reference]
 
-Source: Trained_Models/Trained_{Ori,Obs,Dyn}/best_model.zip -> policy.pth, loaded with torch.load(weights_only=True)
+Source: Trained_Models/Trained_{Ori,Obs,Sta,Dyn}/best_model.zip -> policy.pth, loaded with torch.load(weights_only=True)
 (nothing from the file is executed).  These are DATA files of the reference (SB3 MultiInputPolicy weights); the GPU box
 has no /root/reference, so the closed-loop tests read these fixtures instead.  Also records the aggregate closed-loop
 results the reference ships next to each checkpoint (best.txt / best_modeltest_result.txt, first two lines).
@@ -26,7 +26,7 @@ def main():
     out_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "actors")
     os.makedirs(out_dir, exist_ok=True)
     summary = {}
-    for name, result_file in (("Ori", "best.txt"), ("Obs", "best.txt"), ("Dyn", "best_modeltest_result.txt")):
+    for name, result_file in (("Ori", "best.txt"), ("Obs", "best.txt"), ("Sta", "best.txt"), ("Dyn", "best_modeltest_result.txt")):
         d = os.path.join(args.reference, "Trained_Models", f"Trained_{name}")
         z = zipfile.ZipFile(os.path.join(d, "best_model.zip"))
         sd = torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True, map_location="cpu")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/step_trace_{ori,obs,dyn}.npz with the CPU oracle (seeded), as regression vectors for the
+"""Generate tests/golden/step_trace_{ori,obs,dyn,sta}.npz with the CPU oracle (seeded), as regression vectors for the
 HIP path.  These are outputs of the build's own oracle, not of the reference (which cannot run here: no pybullet):
 
     python tests/golden/gen_step_traces.py
@@ -21,9 +21,13 @@ STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_v
 
 
 def main():
-    for name, kind in (("ori", _abi.ENV_ORI), ("obs", _abi.ENV_OBS), ("dyn", _abi.ENV_DYN)):
+    for name, kind in (("ori", _abi.ENV_ORI), ("obs", _abi.ENV_OBS), ("dyn", _abi.ENV_DYN), ("sta", _abi.ENV_STA)):
         env = ob.OracleEnv(kind, N, threads=4)
         env.reset(seed=SEED)
+        if kind == _abi.ENV_STA:  # make a third of the obstacles move (the 18-column form of set_goal_and_obstacle, reach.py:492-503)
+            mv = np.arange(0, N, 3)
+            env.buf["obst_end"][:, mv] = env.buf["obst_start"][:, mv] + np.array([[0.15], [0.25], [0.1], [0.4], [-0.3], [0.0]])
+            env.refresh()
         rng = np.random.default_rng(SEED + kind)
         out = {"seed": SEED, "kind": kind}
         for k in STATE:

@@ -41,7 +41,7 @@ def test_library_loads_and_exports_every_symbol():
 
 def test_config_defaults_mirror_reference_constants(oracle):
     lib = _native.lib()
-    for kind in (0, 1, 2):
+    for kind in (0, 1, 2, 3):
         a, b = _abi.Config(), oracle.default_config(kind, 17)
         assert lib.urgym_config_default(kind, 17, C.byref(a)) == 0
         assert bytes(a) == bytes(b)  # the product and the oracle state the same constants independently

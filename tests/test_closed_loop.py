@@ -7,10 +7,14 @@ restatement means the same thing as the reference.  Measured with the oracle (CP
 
     UR5OriReach-v1   reference 97.28 %  /  this build 97.2 %    (5250 trials: goal grid x 5 orientations)
     UR5DynReach-v1   reference 96.24 %  /  this build 96.0 %    (3675 trials: goal grid x 5 obstacle draws)
+    UR5StaReach-v1   reference 89.44 %  /  this build ~60 %     (5000 resets)  <- KNOWN GAP
     UR5ObsReach-v1   reference 95.90 %  /  this build ~65 %     (5000 resets)  <- KNOWN GAP, see DESIGN.md §3:
-        the failures are table contacts of forearm / wrist-1 at goals below z = 0 and hovering 6-8 cm from the goal.
-        Obs is the one task whose target is a collidable sphere (reach.py:270-277) sitting 2 cm above a collidable
-        table; the contact dynamics of stepSimulation that shape this policy are not modelled.
+        both older checkpoints drive the arm to a FIXED POINT (zero action) 5-9 cm / 0.04-0.16 rad from the goal, i.e.
+        just outside the success zone (0.05 m, 0.0873 rad) of the current code in a third of the trials; with thresholds
+        (0.1 m, 0.2 rad) the Sta replay gives 91 % in 10 steps.  Obs additionally ends 28 % of its episodes in table
+        contacts of forearm / wrist-1 at goals below z = 0 (its target is a collidable sphere 2 cm above a collidable
+        table: contact dynamics of stepSimulation, SURVEY.md §7 H4-ii, are not modelled).  These two checkpoints appear
+        to predate the present thresholds / scene of the reference; they are reported, not used as pins.
 
 The per-trial test points of the reference were drawn from unseeded RNGs and never saved, so only the aggregates are
 comparable; the tolerances below are a few standard errors of a binomial proportion.
@@ -112,6 +116,24 @@ def test_dyn_actor_closed_loop_oracle(oracle):
     env.close()
 
 
+def test_sta_actor_closed_loop_oracle(oracle):
+    """UR5StaReach-v1: generate_sta = 5000 x task.reset() (utils/generate.py:47-56)."""
+    env = oracle.OracleEnv(_abi.ENV_STA, 1200, threads=8, auto_reset=0)
+    env.reset(seed=5)
+    res = run_closed_loop(OracleBackend(env), DeterministicActor.load(os.path.join(ACTORS, "actor_sta.npz")))
+    print("Sta closed loop (oracle):", {k: res[k] for k in ("success_rate_percent", "mean_episode_reward", "mean_last_step_index")}, "reference:", REF["sta"])
+    # documented gap (module docstring): reported, loosely bounded
+    assert 45.0 < res["success_rate_percent"] <= 100.0
+    env.close()
+    # with the looser thresholds the policy's fixed point falls inside the success zone
+    env = oracle.OracleEnv(_abi.ENV_STA, 600, threads=8, auto_reset=0, distance_threshold=0.1, ori_threshold=0.2)
+    env.reset(seed=5)
+    loose = run_closed_loop(OracleBackend(env), DeterministicActor.load(os.path.join(ACTORS, "actor_sta.npz")))
+    print("Sta closed loop (oracle, thresholds 0.1 m / 0.2 rad):", loose["success_rate_percent"], loose["mean_last_step_index"])
+    assert loose["success_rate_percent"] > 85.0
+    env.close()
+
+
 def test_obs_actor_closed_loop_oracle_known_gap(oracle):
     env = oracle.OracleEnv(_abi.ENV_OBS, 1000, threads=8, auto_reset=0)
     env.reset(seed=2)  # generate_obs = 5000 x task.reset() (utils/generate.py:91-102)
@@ -170,13 +192,19 @@ def test_closed_loop_hip_full_protocol():
     out["dyn"] = run_closed_loop(HipBackend(env), DeterministicActor.load(os.path.join(ACTORS, "actor_dyn.npz")))
     env.close()
 
+    # Sta: 5000 resets
+    env = make_vec("UR5StaReach-v1", num_envs=5000, device="cuda:0", seed=5, auto_reset=False)
+    env.reset(seed=5)
+    out["sta"] = run_closed_loop(HipBackend(env), DeterministicActor.load(os.path.join(ACTORS, "actor_sta.npz")))
+    env.close()
+
     # Obs: 5000 resets (known gap, reported only)
     env = make_vec("UR5ObsReach-v1", num_envs=5000, device="cuda:0", seed=2, auto_reset=False)
     env.reset(seed=2)
     out["obs"] = run_closed_loop(HipBackend(env), DeterministicActor.load(os.path.join(ACTORS, "actor_obs.npz")))
     env.close()
 
-    for k in ("ori", "dyn", "obs"):
+    for k in ("ori", "dyn", "sta", "obs"):
         r = out[k]
         print(f"{k} closed loop (HIP): success {r['success_rate_percent']:.2f}%  reward {r['mean_episode_reward']:.2f}  "
               f"last step {r['mean_last_step_index']:.2f}   reference: {REF[k]}")
@@ -185,4 +213,5 @@ def test_closed_loop_hip_full_protocol():
     assert abs(out["dyn"]["success_rate_percent"] - REF["dyn"]["success_rate_percent"]) < 2.0
     assert abs(out["ori"]["mean_last_step_index"] - REF["ori"]["mean_last_step_index"]) < 1.0
     assert abs(out["dyn"]["mean_last_step_index"] - REF["dyn"]["mean_last_step_index"]) < 1.0
-    assert 50.0 < out["obs"]["success_rate_percent"] <= 100.0
+    assert 45.0 < out["sta"]["success_rate_percent"] <= 100.0  # known gap, reported
+    assert 50.0 < out["obs"]["success_rate_percent"] <= 100.0  # known gap, reported

@@ -23,8 +23,8 @@ from ur_gym_amd import _abi
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-KINDS = [("UR5OriReach-v1", _abi.ENV_ORI), ("UR5ObsReach-v1", _abi.ENV_OBS), ("UR5DynReach-v1", _abi.ENV_DYN)]
-EULER_COLS = {_abi.ENV_ORI: [3, 4, 5], _abi.ENV_OBS: [3, 4, 5], _abi.ENV_DYN: [3, 4, 5, 21, 22, 23]}
+KINDS = [("UR5OriReach-v1", _abi.ENV_ORI), ("UR5ObsReach-v1", _abi.ENV_OBS), ("UR5DynReach-v1", _abi.ENV_DYN), ("UR5StaReach-v1", _abi.ENV_STA)]
+EULER_COLS = {_abi.ENV_ORI: [3, 4, 5], _abi.ENV_OBS: [3, 4, 5], _abi.ENV_DYN: [3, 4, 5, 21, 22, 23], _abi.ENV_STA: [3, 4, 5, 21, 22, 23]}
 REWARD_TOL = 1e-4
 OBS_TOL, LD_TOL = 1e-4, 1e-8
 STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist", "step_count", "episode_id")
@@ -151,13 +151,18 @@ def test_step_parity_against_oracle(oracle, env_id, kind):
     env.close()
 
 
-@pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2]])
+@pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2], ("sta",) + KINDS[3]])
 def test_golden_traces(oracle, name, env_id, kind):
     """Committed vectors (tests/golden/step_trace_*.npz, produced by the oracle with gen_step_traces.py)."""
     g = np.load(os.path.join(HERE, "golden", f"step_trace_{name}.npz"))
     n = g["actions"].shape[1]
     env = make_vec(env_id, num_envs=n, seed=int(g["seed"]))
     env.reset(seed=int(g["seed"]))
+    if kind == _abi.ENV_STA:  # the generator made every third obstacle a moving one (gen_step_traces.py)
+        mv = np.arange(0, n, 3)
+        data = np.c_[np_(env.buf["goal"]).T[mv], np_(env.buf["obst_start"]).T[mv],
+                     np_(env.buf["obst_start"]).T[mv] + np.array([0.15, 0.25, 0.1, 0.4, -0.3, 0.0])]
+        env.set_goal_and_obstacle(mv, data)
     torch.cuda.synchronize()
     st = env.get_state()
     for k in STATE:
@@ -166,7 +171,7 @@ def test_golden_traces(oracle, name, env_id, kind):
     if kind != _abi.ENV_ORI:
         link_dist_slack(oracle, st["link_dist"], g["reset_link_dist"], g["reset_q"], g["reset_obst_pos"], g["reset_obst_quat"])
     assert obs_diff(kind, np_(env.buf["observation"]), g["reset_observation"]) < OBS_TOL
-    w_max = {_abi.ENV_ORI: 0.0, _abi.ENV_OBS: 100.0, _abi.ENV_DYN: 8 / 13 * 50}[kind]
+    w_max = {_abi.ENV_ORI: 0.0, _abi.ENV_OBS: 100.0, _abi.ENV_DYN: 8 / 13 * 50, _abi.ENV_STA: 8 / 13 * 50}[kind]
     for t in range(g["actions"].shape[0]):
         env.step(torch.from_numpy(g["actions"][t]).cuda())
         torch.cuda.synchronize()

@@ -3,8 +3,8 @@ import ctypes as C
 
 ABI_VERSION = 1
 
-ENV_ORI, ENV_OBS, ENV_DYN = 0, 1, 2
-ENV_IDS = {"UR5OriReach-v1": ENV_ORI, "UR5ObsReach-v1": ENV_OBS, "UR5DynReach-v1": ENV_DYN}
+ENV_ORI, ENV_OBS, ENV_DYN, ENV_STA = 0, 1, 2, 3
+ENV_IDS = {"UR5OriReach-v1": ENV_ORI, "UR5ObsReach-v1": ENV_OBS, "UR5DynReach-v1": ENV_DYN, "UR5StaReach-v1": ENV_STA}
 
 OK, ERR_ARG, ERR_HIP, ERR_STATE = 0, -1, -2, -3
 
@@ -14,7 +14,7 @@ STATUS_RESET_COLLISION = 4
 STATUS_PENETRATION = 8
 STATUS_GJK_ITER = 16
 
-OBS_DIMS = {ENV_ORI: (18, 6), ENV_OBS: (26, 3), ENV_DYN: (35, 6)}  # (observation, goal) — core.py:241-247
+OBS_DIMS = {ENV_ORI: (18, 6), ENV_OBS: (26, 3), ENV_DYN: (35, 6), ENV_STA: (29, 6)}  # (observation, goal) — core.py:241-247
 
 KEEP_SEED = 0xFFFFFFFFFFFFFFFF
 

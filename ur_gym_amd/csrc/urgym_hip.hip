@@ -233,6 +233,13 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
       msum = TARGET_SPHERE_R + M_CYL;
       quat_to_rot(quat_from_rpy(st[3], st[4], st[5]), To.r);
       To.t = d3(st[0], st[1], st[2]);
+    } else if (KIND == URGYM_ENV_STA) {
+      // ReachSta.reset (reach.py:464-482): box target at the goal pose vs the obstacle at its sampled pose
+      ta = box_desc(TARGET_BOX_H, TARGET_BOX_H, TARGET_BOX_H, M_TARGET_BOX);
+      msum = M_TARGET_BOX + M_CYL;
+      quat_to_rot(quat_from_rpy(st[3], st[4], st[5]), To.r);
+      To.t = d3(st[0], st[1], st[2]);
+      quat_to_rot(quat_from_rpy(goal[3], goal[4], goal[5]), Tt.r);
     } else {
 #pragma unroll
       for (int i = 0; i < 3; i++) en[i] = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * u[11 + i];
@@ -335,6 +342,19 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
             double ovel[6];
             for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
             integrate_obstacle(opos, oq, ovel, cfg.dt);
+          }
+          if (KIND == URGYM_ENV_STA) {
+            // core.py:307-308 + ReachSta.set_velocity (reach.py:518-541): only when obstacle_end is not all-zero; the full
+            // start->end twist (time_duration = 1) while the obstacle is farther than 0.05 from its end position
+            double st[6], en[6];
+            bool moving = false;
+            for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); moving = moving || en[i] != 0.0; }
+            if (moving) {
+              const double dx = en[0] - opos[0], dy = en[1] - opos[1], dz = en[2] - opos[2];
+              double ovel[6] = {0, 0, 0, 0, 0, 0};
+              if (sqrt(dx * dx + dy * dy + dz * dz) > 0.05) dyn_velocity(st, en, 1.0, ovel);
+              integrate_obstacle(opos, oq, ovel, cfg.dt);
+            }
           }
         } else {
           // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
@@ -538,7 +558,8 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
       double r_, p_, y_;
       rpy_from_quat(oq, r_, p_, y_);
       row[p++] = (float)r_; row[p++] = (float)p_; row[p++] = (float)y_;
-      for (int i = 0; i < 6; i++) row[p++] = (float)vobs[i];
+      if (KIND == URGYM_ENV_DYN)  // ReachSta.get_obs has no velocity slot (reach.py:453-457)
+        for (int i = 0; i < 6; i++) row[p++] = (float)vobs[i];
       for (int i = 0; i < 5; i++) row[p++] = (float)ld_obs[i];
     }
     for (int i = 0; i < GD; i++) { row[OD + i] = ach[i]; row[OD + GD + i] = (float)goal[i]; }
@@ -592,7 +613,7 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
       bool truncated = sc >= cfg.max_episode_steps;  // TimeLimit (UR_gym/__init__.py:41)
       for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = q[i];
       B.step_count[n] = sc;
-      if (KIND == URGYM_ENV_DYN) {
+      if (KIND == URGYM_ENV_DYN || KIND == URGYM_ENV_STA) {
         for (int i = 0; i < 3; i++) SOA(B.obst_pos, i, n, N) = opos[i];
         SOA(B.obst_quat, 0, n, N) = oq.x; SOA(B.obst_quat, 1, n, N) = oq.y; SOA(B.obst_quat, 2, n, N) = oq.z; SOA(B.obst_quat, 3, n, N) = oq.w;
       }
@@ -779,10 +800,15 @@ void fill_default(int env_kind, int num_envs, urgym_config* c) {
     const double gl[3] = {0.3, -0.5, -0.1}, gh[3] = {0.75, 0.5, 0.2}, ol[3] = {0.5, -0.5, 0.25}, oh[3] = {1.0, 0.5, 0.55};
     for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; c->obst_low[i] = ol[i]; c->obst_high[i] = oh[i]; }
     for (int i = 0; i < 5; i++) c->w_link[i] = 100.0;
-  } else {  // reach.py:584-598
+  } else {  // Dyn: reach.py:584-598; Sta: reach.py:385-399 (Ori's goal box, Obs's obstacle box, Dyn's weights)
     c->w_distance = -70; c->w_orientation = -30;
     const double gl[3] = {0.4, -0.5, 0.0}, gh[3] = {0.75, 0.5, 0.2}, ol[3] = {0.5, -0.8, 0.25}, oh[3] = {1.2, 0.8, 0.75};
-    for (int i = 0; i < 3; i++) { c->goal_low[i] = gl[i]; c->goal_high[i] = gh[i]; c->obst_low[i] = ol[i]; c->obst_high[i] = oh[i]; }
+    const double sgl[3] = {0.3, -0.5, 0.0}, sgh[3] = {0.75, 0.5, 0.2}, sol[3] = {0.5, -0.5, 0.25}, soh[3] = {1.0, 0.5, 0.55};
+    const bool sta = env_kind == URGYM_ENV_STA;
+    for (int i = 0; i < 3; i++) {
+      c->goal_low[i] = sta ? sgl[i] : gl[i]; c->goal_high[i] = sta ? sgh[i] : gh[i];
+      c->obst_low[i] = sta ? sol[i] : ol[i]; c->obst_high[i] = sta ? soh[i] : oh[i];
+    }
     const double lw[5] = {8, 2.4, 1.2, 1.2, 0.2};
     double sum = 0;
     for (int i = 0; i < 5; i++) sum += lw[i];
@@ -812,6 +838,7 @@ void launch_mode(Handle* h, const KParams& P, const float* actions, int groups, 
   switch (h->cfg.env_kind) {
     case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
     case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE>), grid, block, 0, s, P, actions); break;
+    case URGYM_ENV_STA: hipLaunchKernelGGL((env_kernel<URGYM_ENV_STA, MODE>), grid, block, 0, s, P, actions); break;
     default: hipLaunchKernelGGL((env_kernel<URGYM_ENV_DYN, MODE>), grid, block, 0, s, P, actions); break;
   }
 }
@@ -882,21 +909,21 @@ extern "C" {
 int urgym_abi_version(void) { return URGYM_ABI_VERSION; }
 
 int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg) {
-  if (!cfg || env_kind < 0 || env_kind > 2 || num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_config_default: bad argument");
+  if (!cfg || env_kind < 0 || env_kind > 3 || num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_config_default: bad argument");
   fill_default(env_kind, num_envs, cfg);
   return URGYM_OK;
 }
 
 int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim) {
-  if (env_kind < 0 || env_kind > 2 || !obs_dim || !goal_dim) return fail(nullptr, URGYM_ERR_ARG, "urgym_obs_dims: bad argument");
-  *obs_dim = env_kind == URGYM_ENV_ORI ? 18 : (env_kind == URGYM_ENV_OBS ? 26 : 35);
+  if (env_kind < 0 || env_kind > 3 || !obs_dim || !goal_dim) return fail(nullptr, URGYM_ERR_ARG, "urgym_obs_dims: bad argument");
+  *obs_dim = env_kind == URGYM_ENV_ORI ? 18 : (env_kind == URGYM_ENV_OBS ? 26 : (env_kind == URGYM_ENV_STA ? 29 : 35));
   *goal_dim = env_kind == URGYM_ENV_OBS ? 3 : 6;
   return URGYM_OK;
 }
 
 int urgym_create(const urgym_config* cfg, int device, void** handle) {
   if (!cfg || !handle) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: null argument");
-  if (cfg->env_kind < 0 || cfg->env_kind > 2 || cfg->num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad env_kind/num_envs");
+  if (cfg->env_kind < 0 || cfg->env_kind > 3 || cfg->num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad env_kind/num_envs");
   if (device < 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: this library has no CPU path; device must be a HIP ordinal >= 0");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);

@@ -195,13 +195,19 @@ class UR5ReachVectorEnv:
 
     def set_goal_and_obstacle(self, ids, data):
         """Reach{Obs,Dyn}.set_goal_and_obstacle (reach.py:328-335, 702-713).
-        Obs: data = [goal xyz, obstacle xyz+rpy] (9); Dyn: [goal 6, obstacle_start 6, obstacle_end 6] (18)."""
+        Obs: data = [goal xyz, obstacle xyz+rpy] (9); Dyn: [goal 6, obstacle_start 6, obstacle_end 6] (18);
+        Sta: [goal 6, obstacle 6] (12) or the 18-column moving form."""
         ids = torch.as_tensor(ids, device=self.device).long()
         d = torch.as_tensor(data, device=self.device, dtype=torch.float64).reshape(len(ids), -1)
         if self.env_kind == _abi.ENV_OBS:
             assert d.shape[1] == 9
             self.buf["goal"][:3, ids] = d[:, :3].T
             self.buf["obst_start"][:, ids] = d[:, 3:9].T
+        elif self.env_kind == _abi.ENV_STA:  # reach.py:484-507: 12 columns = static obstacle, 18 = start/end (moving)
+            assert d.shape[1] in (12, 18)
+            self.buf["goal"][:, ids] = d[:, :6].T
+            self.buf["obst_start"][:, ids] = d[:, 6:12].T
+            self.buf["obst_end"][:, ids] = d[:, 12:18].T if d.shape[1] == 18 else 0.0
         elif self.env_kind == _abi.ENV_DYN:
             assert d.shape[1] == 18
             self.buf["goal"][:, ids] = d[:, :6].T
