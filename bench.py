@@ -27,7 +27,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418}
+ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418, "UR5StaReach-v1": 370}  # SURVEY.md §8(d); Sta = Dyn without the velocity slots
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command
 

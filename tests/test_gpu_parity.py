@@ -274,6 +274,49 @@ def test_set_goal_and_obstacle_parity(oracle):
     env.close()
 
 
+def test_device_closest_distance_primitives(oracle):
+    """urgym_probe_closest: the device GJK on every shape pairing the path uses (hull<->cylinder: link distances;
+    hull<->box: table/track; hull<->hull: self collision; box/sphere<->cylinder: reset clearance), incl. Bullet's
+    early-out for the boolean queries, against the oracle's restatement of p.getClosestPoints."""
+    from scipy.spatial.transform import Rotation as Rot
+
+    env = make_vec("UR5DynReach-v1", num_envs=64, seed=1)
+    rng = np.random.default_rng(7)
+    n = 1500
+    H, C_, B_, S_ = oracle.HULL, oracle.CYLZ, oracle.BOX, oracle.SPHERE
+    cases = []
+    for i in range(n):
+        pa = np.r_[rng.uniform(-0.5, 0.5, 3) + [0.5, 0, 0.35], Rot.random(random_state=int(rng.integers(1 << 30))).as_quat()]
+        pb = np.r_[rng.uniform(-0.3, 0.3, 3) + [0.6, 0, 0.3], Rot.random(random_state=int(rng.integers(1 << 30))).as_quat()]
+        kind = i % 6
+        if kind == 0: cases.append((H, [int(rng.integers(1, 7)), 0, 0], pa, C_, [0.05, 0.4, 0], pb, 5.0))
+        elif kind == 1: cases.append((H, [int(rng.integers(2, 7)), 0, 0], pa, B_, [0.55, 0.9, 0.46], np.r_[0.5, 0, -0.58, 0, 0, 0, 1], 0.01))
+        elif kind == 2: cases.append((H, [int(rng.integers(2, 7)), 0, 0], pa, B_, [0.1, 0.55, 0.06], np.r_[0, 0, -0.06, 0, 0, 0, 1], 5.0))
+        elif kind == 3: cases.append((H, [int(rng.integers(1, 4)), 0, 0], pa, H, [int(rng.integers(3, 7)), 0, 0], pb, 5.0))
+        elif kind == 4: cases.append((B_, [0.025, 0.025, 0.025], pa, C_, [0.05, 0.4, 0], pb, 5.0))
+        else: cases.append((S_, [0.02, 0, 0], pa, C_, [0.05, 0.4, 0], pb, 5.0))
+    for thr in (5.0, 0.01):
+        sel = [c for c in cases if c[6] == thr]
+        d, info = env.probe_closest([c[0] for c in sel], [c[1] for c in sel], [c[2] for c in sel], [c[3] for c in sel],
+                                    [c[4] for c in sel], [c[5] for c in sel], threshold=thr)
+        bad = 0
+        for k, c in enumerate(sel):
+            ref = oracle.closest(c[0], c[1], c[2], c[3], c[4], c[5], threshold=thr)
+            if ref["penetrating"]:
+                assert info[k] & 1, (k, ref)       # both sides see overlapping cores
+                continue
+            if thr < 1.0:                           # boolean query: agree on "closer than the threshold"
+                hit = (not (info[k] & 4)) and d[k] <= thr
+                assert hit == ref["has_point"], (k, c, d[k], info[k], ref)
+                if not ref["has_point"]:
+                    continue
+            if abs(d[k] - ref["distance"]) > LD_TOL:
+                bad += 1                            # ill-conditioned query (module docstring): must stay rare and small
+                assert abs(d[k] - ref["distance"]) < 1e-4
+        assert bad <= max(3, len(sel) // 200)
+    env.close()
+
+
 def test_rollout_equals_stepwise():
     n, k = 256, 15
     a = torch.rand((k, n, 6), device="cuda:0") * 2 - 1

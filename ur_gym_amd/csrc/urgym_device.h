@@ -352,121 +352,151 @@ constexpr int GJK_SLOT_DOUBLES = 24;
 __device__ __forceinline__ D3 ldw(XRef T, int i) { return d3(T.at(12 + 3 * i), T.at(13 + 3 * i), T.at(14 + 3 * i)); }
 __device__ __forceinline__ void stw(XRef T, int i, D3 w) { T.set(12 + 3 * i, w.x); T.set(13 + 3 * i, w.y); T.set(14 + 3 * i, w.z); }
 
-__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
-                                                    D3 v0, double max_d, int& info) {
+// The search is RESUMABLE (gjk_begin + one gjk_iterate per loop trip) so that a lane can finish one query and start
+// another while its wave keeps iterating: the kernels use that to let lanes that are done early pick up queued work.
+struct GjkRun {
+  D3 v;             // Bullet's m_cachedSeparatingAxis
+  double sq;        // squaredDistance
+  double max_d2;
+  int n;            // simplex size (vertices in the LDS slot)
+  int iter;
+  int curA, curB;   // warm starts of the two hull searches
+  int info;         // GJK_* flags, valid when done
+  double core;      // result (core distance), valid when done
+  bool done;
+};
+__device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0, double max_d) {
+  r.v = v0;
+  r.sq = 1.0e300;
+  r.max_d2 = max_d * max_d;
+  r.n = 0;
+  r.iter = 0;
+  r.curA = r.curB = -1;
+  r.info = 0;
+  r.core = 0.0;
+  r.done = false;
+}
+// exit of the search: what Bullet does after its loop (checkSimplex / degenerate cases)
+__device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int degenerate) {
+  const double REL_ERROR2 = 1.0e-12;
+  const double l2 = len2(r.v);
+  r.done = true;
+  if (!check_simplex || l2 < REL_ERROR2) {
+    if (!(r.info & GJK_ITERCAP)) r.info |= GJK_PENETRATING;
+    r.core = 0.0;
+    return;
+  }
+  if (degenerate == 10) r.info |= GJK_SEPARATED;
+  r.core = sqrt(l2);
+}
+// one iteration of btGjkPairDetector's loop
+__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
-  info = 0;
-  D3 v = v0;
-  double sq = 1.0e300;
-  const double max_d2 = max_d * max_d;
-  int n = 0;
-  bool check_simplex = false;
-  int degenerate = 0;
-  int iter = 0;
-  int curA = -1, curB = -1;  // warm starts of the two hull searches
-  for (;;) {
-    D3 w;
-    {
-      D3 p = apply(T, support_local(g, A, rotT(T, -v), curA));
-      D3 q = support_local(g, B, v, curB);
-      w = p - q;
-    }
-    double delta = dot(v, w);
-    if (delta > 0.0 && delta * delta > sq * max_d2) { degenerate = 10; check_simplex = true; break; }
-    {
-      bool in = false;
-      for (int i = 0; i < n; i++) in = in || (len2(ldw(T, i) - w) <= 1e-12);
-      if (in) { degenerate = 1; check_simplex = true; break; }
-    }
-    double f0 = sq - delta, f1 = sq * REL_ERROR2;
-    if (f0 <= f1) { degenerate = (f0 <= 0.0) ? 2 : 11; check_simplex = true; break; }
-    stw(T, n, w);
-    n++;
-    // ---- closest point of the simplex to the origin + vertex reduction
-    D3 nv = d3(0, 0, 0);
-    bool valid = true;
-    bool ua = true, ub = true, uc = true, ud = true;
-    bool reduce = true;
-    if (n == 1) {
-      nv = w;
-      reduce = false;
-    } else if (n == 2) {
-      D3 s0 = ldw(T, 0);
-      D3 e = w - s0;
-      double t = -dot(e, s0);
-      if (t > 0.0) {
-        double ee = dot(e, e);
-        if (t < ee) t /= ee;
-        else { t = 1.0; ua = false; }
-      } else {
-        t = 0.0;
-        ub = false;
-      }
-      nv = s0 + e * t;
-      uc = ud = false;
-    } else if (n == 3) {
-      int m;
-      nv = tri_closest(ldw(T, 0), ldw(T, 1), w, m);
-      ua = m & 1; ub = m & 2; uc = m & 4; ud = false;
+  D3 w;
+  {
+    D3 p = apply(T, support_local(g, A, rotT(T, -r.v), r.curA));
+    D3 q = support_local(g, B, r.v, r.curB);
+    w = p - q;
+  }
+  const double delta = dot(r.v, w);
+  if (delta > 0.0 && delta * delta > r.sq * r.max_d2) { gjk_finish(r, true, 10); return; }
+  {
+    bool in = false;
+    for (int i = 0; i < r.n; i++) in = in || (len2(ldw(T, i) - w) <= 1e-12);
+    if (in) { gjk_finish(r, true, 1); return; }
+  }
+  const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;
+  if (f0 <= f1) { gjk_finish(r, true, (f0 <= 0.0) ? 2 : 11); return; }
+  stw(T, r.n, w);
+  int n = r.n + 1;
+  // ---- closest point of the simplex to the origin + vertex reduction
+  D3 nv = d3(0, 0, 0);
+  bool valid = true;
+  bool ua = true, ub = true, uc = true, ud = true;
+  bool reduce = true;
+  if (n == 1) {
+    nv = w;
+    reduce = false;
+  } else if (n == 2) {
+    D3 s0 = ldw(T, 0);
+    D3 e = w - s0;
+    double t = -dot(e, s0);
+    if (t > 0.0) {
+      double ee = dot(e, e);
+      if (t < ee) t /= ee;
+      else { t = 1.0; ua = false; }
     } else {
-      // faces in Bullet's order: ABC|D, ACD|B, ADB|C, BDC|A
-      double best = 1.0e300;
-      bool any_out = false, degen = false;
-      ua = ub = uc = ud = false;
+      t = 0.0;
+      ub = false;
+    }
+    nv = s0 + e * t;
+    uc = ud = false;
+  } else if (n == 3) {
+    int m;
+    nv = tri_closest(ldw(T, 0), ldw(T, 1), w, m);
+    ua = m & 1; ub = m & 2; uc = m & 4; ud = false;
+  } else {
+    // faces in Bullet's order: ABC|D, ACD|B, ADB|C, BDC|A
+    double best = 1.0e300;
+    bool any_out = false, degen = false;
+    ua = ub = uc = ud = false;
 #pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        const int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
-        const int io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
-        D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
-        D3 nrm = cross(b - a, c - a);
-        double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
-        if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
-        else if (signp * signd < 0.0) {
-          int m3;
-          D3 pt = tri_closest(a, b, c, m3);
-          double l = len2(pt);
-          if (!any_out || l < best) {
-            best = l;
-            nv = pt;
-            const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
-            ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
-          }
-          any_out = true;
+    for (int f = 0; f < 4; f++) {
+      const int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
+      const int io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
+      D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
+      D3 nrm = cross(b - a, c - a);
+      double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
+      if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
+      else if (signp * signd < 0.0) {
+        int m3;
+        D3 pt = tri_closest(a, b, c, m3);
+        double l = len2(pt);
+        if (!any_out || l < best) {
+          best = l;
+          nv = pt;
+          const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+          ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
         }
-      }
-      if (degen) {
-        valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
-        reduce = false;
-      } else if (!any_out) {
-        nv = d3(0, 0, 0);  // origin inside the tetrahedron
-        reduce = false;
+        any_out = true;
       }
     }
-    if (reduce) {
-      // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
-      if (n >= 4 && !ud) { n--; }
-      if (n >= 3 && !uc) { n--; stw(T, 2, ldw(T, n)); }
-      if (n >= 2 && !ub) { n--; stw(T, 1, ldw(T, n)); }
-      if (n >= 1 && !ua) { n--; stw(T, 0, ldw(T, n)); }
+    if (degen) {
+      valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
+      reduce = false;
+    } else if (!any_out) {
+      nv = d3(0, 0, 0);  // origin inside the tetrahedron
+      reduce = false;
     }
-    if (!valid) { degenerate = 3; check_simplex = true; break; }
-    double nsq = len2(nv);
-    if (nsq < REL_ERROR2) { v = nv; degenerate = 6; check_simplex = true; break; }
-    double prev = sq;
-    sq = nsq;
-    if (prev - sq <= EPS * prev) { degenerate = 12; check_simplex = true; break; }
-    v = nv;
-    if (iter++ > 1000) { info |= GJK_ITERCAP; break; }
-    if (n == 4) { degenerate = 13; break; }
   }
-  double l2 = len2(v);
-  if (!check_simplex || l2 < REL_ERROR2) {
-    if (!(info & GJK_ITERCAP)) info |= GJK_PENETRATING;
-    return 0.0;
+  if (reduce) {
+    // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
+    if (n >= 4 && !ud) { n--; }
+    if (n >= 3 && !uc) { n--; stw(T, 2, ldw(T, n)); }
+    if (n >= 2 && !ub) { n--; stw(T, 1, ldw(T, n)); }
+    if (n >= 1 && !ua) { n--; stw(T, 0, ldw(T, n)); }
   }
-  if (degenerate == 10) info |= GJK_SEPARATED;
-  return sqrt(l2);
+  r.n = n;
+  if (!valid) { gjk_finish(r, true, 3); return; }
+  const double nsq = len2(nv);
+  if (nsq < REL_ERROR2) { r.v = nv; gjk_finish(r, true, 6); return; }
+  const double prev = r.sq;
+  r.sq = nsq;
+  if (prev - nsq <= EPS * prev) { gjk_finish(r, true, 12); return; }
+  r.v = nv;
+  if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; gjk_finish(r, false, 0); return; }
+  if (n == 4) { gjk_finish(r, false, 13); return; }
+}
+
+// convenience wrapper: run one query to the end
+__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
+                                                    D3 v0, double max_d, int& info) {
+  GjkRun r;
+  gjk_begin(r, v0, max_d);
+  while (!r.done) gjk_iterate(r, g, A, T, B);
+  info = r.info;
+  return r.core;
 }
 
 }  // namespace urgym

@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
   __shared__ double s_sc[12][ENVS_PER_GROUP];   // sin (0..5) and cos (6..11) of those joints: computed once, used by every FK
   __shared__ double s_obst[7][ENVS_PER_GROUP];  // obstacle position + quaternion of the step (after its motion)
   __shared__ uint32_t s_queue[QUEUE_CAP];
-  __shared__ int s_qcount;
+  __shared__ int s_qcount, s_qhead;
   __shared__ int s_coll[ENVS_PER_GROUP];
   __shared__ int s_flags[ENVS_PER_GROUP];
   __shared__ int s_env[ENVS_PER_GROUP];         // global env id of slot e, -1 = empty slot
@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
     if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
     s_flags[lane] = flags;
     s_coll[lane] = 0;
-    if (lane == 0) s_qcount = 0;
+    if (lane == 0) { s_qcount = 0; s_qhead = 0; }
     double q[6] = {0, 0, 0, 0, 0, 0};
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
@@ -375,113 +375,122 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
   }
   __syncthreads();
 
-  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined GJK body.  Each work item rebuilds its
-  // transforms from the joint vector in LDS, so nothing but loop counters is live across the GJK.
-  //   round 0 : lane (env e, link L = wave + 2): float64 FK to link L, capsule culling of the table / track / self
-  //             pairs that involve L (pyb_setup.py:407-427; survivors -> LDS queue), then the exact distance
-  //             hull(L) <-> obstacle cylinder (pyb_setup.py:439-456, also the obstacle rule of check_collision)
-  //   round 1+: the queued (rare) pairs, one per lane across the whole group: boolean "closer than the margin?"
+  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined, resumable GJK body.
+  //   setup   : lane (env e, link L = wave + 2): float64 FK to link L, bounding-capsule culling of the table / track /
+  //             self pairs that involve L (pyb_setup.py:407-427; survivors -> LDS queue), pose of hull L in the obstacle
+  //             frame -> the lane's LDS slot
+  //   iterate : every lane advances its query by one GJK iteration per loop trip: first the exact distance
+  //             hull(L) <-> obstacle cylinder (pyb_setup.py:439-456, also the obstacle rule of check_collision); a lane
+  //             that is done takes the next queued (rare) pair — boolean "closer than the margin?" — so those pairs are
+  //             worked off in the shadow of the slowest obstacle queries instead of in extra, almost empty rounds
   {
-    for (int round = 0;; round++) {
-      if (round == 1) __syncthreads();                         // the queue is complete
-      if (round >= 1 && (round - 1) * THREADS >= s_qcount) break;  // uniform: every thread reads the same count
-      uint32_t item;
-      bool have;
-      if (round == 0) {
-        have = s_env[lane] >= 0 && (HAS_OBST || (cfg.check_collision && MODE != MODE_RESET));
-        item = (uint32_t)lane | (3u << 6) | ((uint32_t)(wv + 2) << 8);
+    ShapeDesc sa = hull_desc(1), sb = cyl_desc();
+    D3 v0 = d3(0, 1, 0);
+    int kind = 3, e = lane, lb = wv + 2;
+    // builds the operands of one work item; returns false when there is nothing to run
+    auto setup = [&](uint32_t item, bool cull) -> bool {
+      e = item & 63;
+      kind = (item >> 6) & 3;
+      lb = (item >> 8) & 7;
+      const int la = (item >> 11) & 7;
+      X3 T = identity_x3(), TA = identity_x3();
+      // FK to link lb; the world capsules of links 1..3 (self-collision culling) are parked in the lane's LDS slot,
+      // which is free until the GJK operand is stored
+#pragma unroll 1
+      for (int k = 0; k < lb; k++) {
+        fk_joint(T, k, s_sc[k][e], s_sc[6 + k][e]);
+        if (k + 1 == la) TA = T;
+        if (k < 3 && cull) {
+          const double* c = c_tab.capsule[k];
+          const D3 c0 = apply(T, d3(c[0], c[1], c[2])), c1 = apply(T, d3(c[3], c[4], c[5]));
+          pose_slot.set(6 * k + 0, c0.x); pose_slot.set(6 * k + 1, c0.y); pose_slot.set(6 * k + 2, c0.z);
+          pose_slot.set(6 * k + 3, c1.x); pose_slot.set(6 * k + 4, c1.y); pose_slot.set(6 * k + 5, c1.z);
+        }
+      }
+      if (kind == 3) {
+        if (cull) {
+          const double* c = c_tab.capsule[lb - 1];
+          D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
+          const double rb = c[6];
+          const double lim = cfg.collision_margin + 1e-6;
+          if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim)
+            s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TABLE << 6) | ((uint32_t)lb << 8);
+          if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim)
+            s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TRACK << 6) | ((uint32_t)lb << 8);
+          // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6), filed under link B
+#pragma unroll 1
+          for (int A = 1; A <= 3 && A <= lb - 2; A++) {
+            const double ra = c_tab.capsule[A - 1][6];
+            const int o = 6 * (A - 1);
+            const D3 a0 = d3(pose_slot.at(o), pose_slot.at(o + 1), pose_slot.at(o + 2));
+            const D3 a1 = d3(pose_slot.at(o + 3), pose_slot.at(o + 4), pose_slot.at(o + 5));
+            if (segseg_dist(a0, a1, b0, b1) - ra - rb <= lim)
+              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
+          }
+        }
+        if (!HAS_OBST) return false;
+        X3 To;
+        quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
+        To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
+        sa = hull_desc(lb);
+        sb = cyl_desc();
+        store(pose_slot, rel(To, T));
+        v0 = rotT(To, d3(0, 1, 0));  // Bullet's pair detector starts from the world +Y axis
+      } else if (kind == Q_SELF) {
+        sa = hull_desc(la);
+        sb = hull_desc(lb);
+        store(pose_slot, rel(T, TA));
+        v0 = rotT(T, d3(0, 1, 0));
       } else {
-        const int it = (round - 1) * THREADS + tid;
-        have = it < s_qcount;
-        item = have ? s_queue[it] : 0u;
+        const bool tbl = (kind == Q_TABLE);
+        sa = hull_desc(lb);
+        sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
+        T.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+        store(pose_slot, T);
+        v0 = d3(0, 1, 0);
       }
-      const int e = item & 63, kind = (item >> 6) & 3, lb = (item >> 8) & 7, la = (item >> 11) & 7;
-      ShapeDesc sa = hull_desc(1), sb = cyl_desc();
-      D3 v0 = d3(0, 1, 0);
-      bool run = false;
-      if (have) {
-        X3 T = identity_x3(), TA = identity_x3();
-        // FK to link lb; the world capsules of links 1..3 (self-collision culling) are parked in the lane's LDS slot,
-        // which is free until the GJK operand is stored
-#pragma unroll 1
-        for (int k = 0; k < lb; k++) {
-          fk_joint(T, k, s_sc[k][e], s_sc[6 + k][e]);
-          if (k + 1 == la) TA = T;
-          if (k < 3 && kind == 3) {
-            const double* c = c_tab.capsule[k];
-            const D3 c0 = apply(T, d3(c[0], c[1], c[2])), c1 = apply(T, d3(c[3], c[4], c[5]));
-            pose_slot.set(6 * k + 0, c0.x); pose_slot.set(6 * k + 1, c0.y); pose_slot.set(6 * k + 2, c0.z);
-            pose_slot.set(6 * k + 3, c1.x); pose_slot.set(6 * k + 4, c1.y); pose_slot.set(6 * k + 5, c1.z);
-          }
-        }
-        if (kind == 3) {
-          // obstacle item: first the conservative culling of the other pairs of this link
-          if (cfg.check_collision && MODE != MODE_RESET) {
-            const double* c = c_tab.capsule[lb - 1];
-            D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
-            const double rb = c[6];
-            const double lim = cfg.collision_margin + 1e-6;
-            if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim)
-              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TABLE << 6) | ((uint32_t)lb << 8);
-            if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim)
-              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TRACK << 6) | ((uint32_t)lb << 8);
-            // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6), filed under link B
-#pragma unroll 1
-            for (int A = 1; A <= 3 && A <= lb - 2; A++) {
-              const double ra = c_tab.capsule[A - 1][6];
-              const int o = 6 * (A - 1);
-              const D3 a0 = d3(pose_slot.at(o), pose_slot.at(o + 1), pose_slot.at(o + 2));
-              const D3 a1 = d3(pose_slot.at(o + 3), pose_slot.at(o + 4), pose_slot.at(o + 5));
-              if (segseg_dist(a0, a1, b0, b1) - ra - rb <= lim)
-                s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
-            }
-          }
-          if (HAS_OBST) {
-            X3 To;
-            quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
-            To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
-            sa = hull_desc(lb);
-            sb = cyl_desc();
-            store(pose_slot, rel(To, T));
-            v0 = rotT(To, d3(0, 1, 0));  // Bullet's pair detector starts from the world +Y axis
-            run = true;
-          }
-        } else {
-          if (kind == Q_SELF) {
-            sa = hull_desc(la);
-            sb = hull_desc(lb);
-            store(pose_slot, rel(T, TA));
-            v0 = rotT(T, d3(0, 1, 0));
+      return true;
+    };
+    // Bullet margins of the pair and its early-out distance (margins + 0.02 + query threshold): get_link_distances
+    // queries with distance=5.0 (pyb_setup.py:452), check_collision with 0.01 (pyb_setup.py:402-422).  Recomputed from
+    // `kind` where needed: nothing constant-like stays live across the search (see DESIGN.md "toolchain hazard").
+    auto margin_sum = [&]() -> double {
+      return M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
+    };
+
+    GjkRun run;
+    bool busy = false;
+    if (s_env[lane] >= 0 && (HAS_OBST || (cfg.check_collision && MODE != MODE_RESET))) {
+      busy = setup((uint32_t)lane | (3u << 6) | ((uint32_t)(wv + 2) << 8), cfg.check_collision && MODE != MODE_RESET);
+      if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + 5.0);
+    }
+    if (!busy && HAS_OBST) s_dist[wv][lane] = (s_env[lane] <= -2) ? __builtin_nan("") : 1e30;
+    __syncthreads();  // the queue of culling survivors is complete
+    for (;;) {
+      if (busy) {
+        gjk_iterate(run, P.graph, sa, pose_slot, sb);
+        if (run.done) {
+          const double msum = margin_sum();
+          if (kind == 3) {
+            double dist = run.core - msum;
+            if (run.info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION); }
+            if (run.info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+            s_dist[lb - 2][e] = dist;
           } else {
-            const bool tbl = (kind == Q_TABLE);
-            sa = hull_desc(lb);
-            sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
-            T.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
-            store(pose_slot, T);
+            const bool hit = (run.info & GJK_PENETRATING) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
+            if (hit) atomicOr(&s_coll[e], 1);
           }
-          run = true;
+          busy = false;
         }
       }
-      if (run) {
-        // Bullet margins of the pair and its early-out distance (margins + 0.02 + query threshold): get_link_distances
-        // queries with distance=5.0 (pyb_setup.py:452), check_collision with 0.01 (pyb_setup.py:402-422)
-        const double mB = (kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK));
-        const double thr = (kind == 3) ? 5.0 : cfg.collision_margin;
-        int info;
-        const double core = gjk_core_distance(P.graph, sa, pose_slot, sb, v0, (M_HULL + mB) + 0.02 + thr, info);
-        const double msum = M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
-        if (kind == 3) {
-          double dist = core - msum;
-          if (info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION); }
-          if (info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
-          s_dist[lb - 2][e] = dist;
-        } else {
-          const bool hit = (info & GJK_PENETRATING) || (!(info & GJK_SEPARATED) && (core - msum) <= cfg.collision_margin);
-          if (hit) atomicOr(&s_coll[e], 1);
+      if (!busy && s_qhead < s_qcount) {
+        const int it = atomicAdd(&s_qhead, 1);
+        if (it < s_qcount) {
+          busy = setup(s_queue[it], false);
+          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + cfg.collision_margin);
         }
-      } else if (round == 0 && HAS_OBST) {
-        s_dist[wv][lane] = (s_env[lane] <= -2) ? __builtin_nan("") : 1e30;
       }
+      if (__ballot(busy) == 0ull) break;  // this wave has nothing left (other waves keep pulling from the queue)
     }
   }
   __syncthreads();
