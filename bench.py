@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--gather-obs", action="store_true", help="all-gather observations over RCCL every step (optional)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gjk-start", choices=("bullet", "guided"), default="bullet",
+                    help="bullet = the reference's search start (parity-grade, default); guided = opt-in, NOT parity-grade")
     ap.add_argument("--rollout", action="store_true", help="enqueue all K steps through urgym_rollout (no Python per step)")
     args = ap.parse_args()
 
@@ -104,7 +106,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     n = args.num_envs
-    env = make_vec(args.env, num_envs=n, device=dev, seed=args.seed + 1000 * rank)
+    env = make_vec(args.env, num_envs=n, device=dev, seed=args.seed + 1000 * rank, gjk_start=int(args.gjk_start == "guided"))
     env.reset(seed=args.seed + 1000 * rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + rank)
@@ -166,7 +168,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.env} N={n} per GPU, random actions U(-1,1), auto-reset, seed {args.seed}",
-                       "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout)},
+                       "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout),
+                       "gjk_start": args.gjk_start},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.env, n),
                          "traffic_source": "profiles/r1/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",

@@ -44,6 +44,19 @@ enum {
   URGYM_ERR_STATE = -3,
 };
 
+/* First separating axis of the GJK closest-point queries of the links (obstacle, table, track, self pairs).
+ * BULLET: the world +Y axis, as btGjkPairDetector is entered by btConvexConvexAlgorithm -- the search then visits the
+ *         same simplices as the reference's Bullet build (default; what every parity test pins).
+ * GUIDED: the line from the other shape's centre to the mid point of the link's bounding capsule -- about half the
+ *         iterations, ~1.6x the step rate.  NOT parity-grade: Bullet's answer is not path-independent (its
+ *         degenerate-simplex / no-progress exits return the current iterate), so on these finely faceted hulls the two
+ *         modes differ by > 1e-6 m on ~1.5 % and > 1e-5 m on ~0.15 % of the queries, worst seen ~1e-4 m.  Opt-in for
+ *         training runs that do not need the reference's exact numbers; see DESIGN.md "GJK start". */
+enum {
+  URGYM_GJK_START_BULLET = 0,
+  URGYM_GJK_START_GUIDED = 1,
+};
+
 /* bits of the per-env status word (device-side anomalies; SURVEY.md §5 "failure detection") */
 enum {
   URGYM_STATUS_NAN = 1,              /* a NaN reached the reward/obs (utils.py:65-67 prints in the reference) */
@@ -62,7 +75,7 @@ typedef struct urgym_config {
   int32_t check_collision;   /* 1: reference behaviour; 0: BASELINE.json configs[1] "FK + reward only" */
   int32_t max_reset_tries;   /* bound on the reference's unbounded rejection loop */
   int32_t dyn_motion_steps;  /* reach.py:735 -> 25 */
-  int32_t reserved0;
+  int32_t gjk_start;         /* URGYM_GJK_START_*: first separating axis of every link query (default BULLET) */
   double action_scale;       /* UR5.py:276,314: pi*0.1 is applied as two float32 products; kept for reporting */
   double dt;                 /* pyb_setup.py:40,47-50: 20 substeps / 500 Hz = 0.04 s */
   double distance_threshold; /* reach.py:148/246/590 -> 0.05 */

@@ -50,7 +50,7 @@ def lib():
         L.urgym_oracle_euler_from_quat.argtypes = [dp, dp]
         L.urgym_oracle_dyn_velocity.argtypes = [dp, dp, C.c_double, dp]
         L.urgym_oracle_closest.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, C.c_double, dp]
-        L.urgym_oracle_query.argtypes = [dp, dp, C.c_int, C.c_double, dp, C.POINTER(C.c_int)]
+        L.urgym_oracle_query.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int, dp, C.POINTER(C.c_int)]
         L.urgym_oracle_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp]
         L.urgym_oracle_hardware_threads.restype = C.c_int
         _lib = L
@@ -193,7 +193,7 @@ def closest(type_a, par_a, pose_a, type_b, par_b, pose_b, threshold=5.0):
     return dict(has_point=bool(out[0]), distance=out[1], penetrating=bool(out[2]), iterations=int(out[3]))
 
 
-def query(q, obst_pose=None, margin=0.01):
+def query(q, obst_pose=None, margin=0.01, gjk_start=0):
     q = np.ascontiguousarray(q, dtype=np.float64)
     ld = np.zeros(5)
     coll = C.c_int(0)
@@ -203,7 +203,7 @@ def query(q, obst_pose=None, margin=0.01):
     else:
         op = np.ascontiguousarray(obst_pose, dtype=np.float64)
         has = 1
-    status = lib().urgym_oracle_query(_dp(q), _dp(op), has, margin, _dp(ld), C.byref(coll))
+    status = lib().urgym_oracle_query(_dp(q), _dp(op), has, margin, int(gjk_start), _dp(ld), C.byref(coll))
     return ld, bool(coll.value), status
 
 

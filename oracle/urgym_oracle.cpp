@@ -483,7 +483,8 @@ struct GjkResult {
 // (REL_ERROR2 = 1e-12), as reached from p.getClosestPoints (pyb_setup.py:401,410,421,436,452) through
 // btCollisionWorld::contactPairTest -> btCompoundCollisionAlgorithm -> btConvexConvexAlgorithm.
 // distance = |closest(core_A - core_B)| - margin_A - margin_B; a point is reported when distance <= threshold.
-GjkResult gjk_distance(const Shape& A, const Shape& B, double threshold) {
+// `start`: first separating axis (world frame, pointing from B to A); nullptr = Bullet's +Y (URGYM_GJK_START_BULLET).
+GjkResult gjk_distance(const Shape& A, const Shape& B, double threshold, const V3* start = nullptr) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
   GjkResult res{false, 0.0, false, 0};
@@ -496,7 +497,7 @@ GjkResult gjk_distance(const Shape& A, const Shape& B, double threshold) {
   // btConvexConvexAlgorithm: maximumDistanceSquared = (marginA + marginB + breakingThreshold(0.02) + threshold)^2
   double max_d = margin + 0.02 + threshold;
   double max_d2 = max_d * max_d;
-  V3 v = v3(0, 1, 0);
+  V3 v = start ? *start : v3(0, 1, 0);
   Simplex s;
   double sq = 1e300;
   bool check_simplex = false;
@@ -595,28 +596,51 @@ struct EnvView {  // pointers to one env's slots in the SoA buffers
   int n, N;
 };
 
+// URGYM_GJK_START_GUIDED (include/urgym.h): unit vector from `centre` to the mid point of the link's bounding capsule
+// (data/ur5e_model.h UR5E_CAPSULE); +Y when the two coincide.  Not part of the reference: an opt-in search start.
+V3 guided_axis(int l, const X3& pose, V3 centre) {
+  const double* c = UR5E_CAPSULE[l - 1];
+  V3 mid = mul(pose.R, v3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]))) + pose.t;
+  V3 d = mid - centre;
+  double n2 = dot(d, d);
+  return n2 > 1e-12 ? d * (1.0 / std::sqrt(n2)) : v3(0, 1, 0);
+}
+V3 capsule_mid(int l, const X3& pose) {
+  const double* c = UR5E_CAPSULE[l - 1];
+  return mul(pose.R, v3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]))) + pose.t;
+}
+
 // PyBullet.get_link_distances (pyb_setup.py:439-456): links 2..6 vs obstacle, distance=5.0
-void link_distances(const X3 link[7], const Shape& obstacle, double out[5], int* status) {
+void link_distances(const X3 link[7], const Shape& obstacle, double out[5], int* status, int gjk_start) {
   for (int i = 0; i < 5; i++) {
-    GjkResult r = gjk_distance(make_hull(i + 2, link[i + 2]), obstacle, 5.0);
+    V3 ax = guided_axis(i + 2, link[i + 2], obstacle.pose.t);
+    GjkResult r = gjk_distance(make_hull(i + 2, link[i + 2]), obstacle, 5.0, gjk_start == URGYM_GJK_START_GUIDED ? &ax : nullptr);
     out[i] = r.distance;
     if (r.penetrating) *status |= URGYM_STATUS_PENETRATION;
     if (r.iterations > 1000) *status |= URGYM_STATUS_GJK_ITER;
   }
 }
 // PyBullet.check_collision (pyb_setup.py:382-429). has_obstacle mirrors `keys[5] == 'obstacle'` (398-399).
-bool check_collision(const X3 link[7], bool has_obstacle, const Shape* obstacle, double margin) {
+bool check_collision(const X3 link[7], bool has_obstacle, const Shape* obstacle, double margin, int gjk_start) {
+  const bool guided = gjk_start == URGYM_GJK_START_GUIDED;
+  V3 ax;
   if (has_obstacle)
-    for (int l = 2; l <= 6; l++)
-      if (gjk_distance(make_hull(l, link[l]), *obstacle, margin).has_point) return true;
+    for (int l = 2; l <= 6; l++) {
+      ax = guided_axis(l, link[l], obstacle->pose.t);
+      if (gjk_distance(make_hull(l, link[l]), *obstacle, margin, guided ? &ax : nullptr).has_point) return true;
+    }
   Shape objs[2] = {scene_table(), scene_track()};
   for (int o = 0; o < 2; o++)
-    for (int l = 2; l <= 6; l++)
-      if (gjk_distance(make_hull(l, link[l]), objs[o], margin).has_point) return true;
+    for (int l = 2; l <= 6; l++) {
+      ax = guided_axis(l, link[l], objs[o].pose.t);
+      if (gjk_distance(make_hull(l, link[l]), objs[o], margin, guided ? &ax : nullptr).has_point) return true;
+    }
   int start = 3;
   for (int la = 1; la < 4; la++) {
-    for (int lb = start; lb < 7; lb++)
-      if (gjk_distance(make_hull(la, link[la]), make_hull(lb, link[lb]), margin).has_point) return true;
+    for (int lb = start; lb < 7; lb++) {
+      ax = guided_axis(la, link[la], capsule_mid(lb, link[lb]));
+      if (gjk_distance(make_hull(la, link[la]), make_hull(lb, link[lb]), margin, guided ? &ax : nullptr).has_point) return true;
+    }
     start++;
   }
   return false;
@@ -835,9 +859,9 @@ void reset_env(Oracle& o, int n) {
     if (c.env_kind == URGYM_ENV_DYN) dyn_velocity(start, end, c.dyn_time_duration, vel);
     for (int i = 0; i < 6; i++) S(b.obst_vel, i, n, N) = vel[i];
     Shape obst = scene_obstacle(obstacle_pose(b, n, N));
-    if (c.check_collision) coll = check_collision(link, true, &obst, c.collision_margin);  // reach.py:323 / 679
+    if (c.check_collision) coll = check_collision(link, true, &obst, c.collision_margin, c.gjk_start);  // reach.py:323 / 679
     double ld[5];
-    link_distances(link, obst, ld, &status);  // reach.py:324-325 / 680-681
+    link_distances(link, obst, ld, &status, c.gjk_start);  // reach.py:324-325 / 680-681
     for (int i = 0; i < 5; i++) S(b.link_dist, i, n, N) = ld[i];
     if (coll) status |= URGYM_STATUS_RESET_COLLISION;
   }
@@ -881,9 +905,9 @@ void refresh_env(Oracle& o, int n) {
     if (c.env_kind == URGYM_ENV_DYN) dyn_velocity(start, end, c.dyn_time_duration, vel);
     for (int i = 0; i < 6; i++) S(b.obst_vel, i, n, N) = vel[i];
     Shape obst = scene_obstacle(obstacle_pose(b, n, N));
-    bool coll = c.check_collision ? check_collision(link, true, &obst, c.collision_margin) : false;
+    bool coll = c.check_collision ? check_collision(link, true, &obst, c.collision_margin, c.gjk_start) : false;
     double ld[5];
-    link_distances(link, obst, ld, &status);
+    link_distances(link, obst, ld, &status, c.gjk_start);
     for (int i = 0; i < 5; i++) S(b.link_dist, i, n, N) = ld[i];
     b.collision[n] = coll ? 1 : 0;
   }
@@ -945,7 +969,7 @@ void step_env(Oracle& o, int n, const float* action) {
   bool has_obst = c.env_kind != URGYM_ENV_ORI;
   Shape obst{};
   if (has_obst) obst = scene_obstacle(obstacle_pose(b, n, N));
-  bool coll = c.check_collision ? check_collision(link, has_obst, has_obst ? &obst : nullptr, c.collision_margin) : false;
+  bool coll = c.check_collision ? check_collision(link, has_obst, has_obst ? &obst : nullptr, c.collision_margin, c.gjk_start) : false;
   // 5. observation (core.py:311) — link_dist still holds the value of the previous compute_reward/reset
   float* obs_row = b.observation + (size_t)n * o.obs_dim;
   float* ach = b.achieved_goal + (size_t)n * o.goal_dim;
@@ -969,7 +993,7 @@ void step_env(Oracle& o, int n, const float* action) {
   } else if (c.env_kind == URGYM_ENV_OBS) {
     // ReachObs.compute_reward (reach.py:356-374)
     double ld[5];
-    link_distances(link, obst, ld, &status);
+    link_distances(link, obst, ld, &status, c.gjk_start);
     reward += succ ? c.w_success : 0.0;
     reward += coll ? c.w_collision : 0.0;
     reward += c.w_distance * d;
@@ -990,7 +1014,7 @@ void step_env(Oracle& o, int n, const float* action) {
       reward += c.w_distance * d;
       reward += c.w_orientation * th;
       double ld[5];
-      link_distances(link, obst, ld, &status);
+      link_distances(link, obst, ld, &status, c.gjk_start);
       double sum = 0.0;
       for (int i = 0; i < 5; i++) {
         double change = ld[i] - S(b.link_dist, i, n, N);
@@ -1038,6 +1062,7 @@ int urgym_oracle_config_default(int env_kind, int num_envs, urgym_config* c) {
   c->auto_reset = 1;
   c->check_collision = 1;
   c->max_reset_tries = 4096;
+  c->gjk_start = URGYM_GJK_START_BULLET;
   c->dyn_motion_steps = 25;
   c->action_scale = M_PI * 0.1;
   c->dt = 20.0 / 500.0;
@@ -1181,7 +1206,7 @@ int urgym_oracle_closest(int type_a, const double* par_a, const double* pose_a, 
   return URGYM_OK;
 }
 // link distances + collision for a joint vector and an obstacle pose (xyz+quat); has_obstacle=0 -> Ori rules
-int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacle, double margin, double* ld5, int* collision) {
+int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacle, double margin, int gjk_start, double* ld5, int* collision) {
   X3 link[7];
   forward_kinematics(q, link);
   int status = 0;
@@ -1189,9 +1214,9 @@ int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacl
   if (has_obstacle) {
     Quat qq{obst_pose[3], obst_pose[4], obst_pose[5], obst_pose[6]};
     obst = scene_obstacle(X3{quat_to_mat(qq), v3(obst_pose[0], obst_pose[1], obst_pose[2])});
-    link_distances(link, obst, ld5, &status);
+    link_distances(link, obst, ld5, &status, gjk_start);
   }
-  *collision = check_collision(link, has_obstacle != 0, has_obstacle ? &obst : nullptr, margin) ? 1 : 0;
+  *collision = check_collision(link, has_obstacle != 0, has_obstacle ? &obst : nullptr, margin, gjk_start) ? 1 : 0;
   return status;
 }
 void urgym_oracle_set_emulation(int flags) { g_emulate = flags; }

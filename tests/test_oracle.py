@@ -408,3 +408,28 @@ def test_demo_style_single_env_loop(oracle):
         resets += int(env.buf["terminated"][0] or env.buf["truncated"][0])
     assert resets >= 3 and env.buf["episode_id"][0] == resets + 1
     env.close()
+
+
+def test_guided_gjk_start_stays_within_path_tolerance(oracle):
+    """urgym_config.gjk_start = GUIDED is an opt-in search start, not the reference's: over random arm / obstacle poses
+    it is NOT inside the 1e-4 m parity tolerance on every query (Bullet's exits return the current iterate, so the answer
+    depends on the search path at the 1e-5 .. 1e-4 level on these finely faceted hulls) and is therefore never the
+    default.  Pinned here: the size of that deviation — < 5e-4 m always, > 1e-5 m on under 0.5 % of queries, > 1e-6 m on
+    under 3 % — and that the collision verdict only moves at knife-edge distances."""
+    rng = np.random.default_rng(11)
+    lo = np.array([-2 * np.pi, -2 * np.pi, -np.pi, -2 * np.pi, -2 * np.pi, -2 * np.pi])
+    worst, over6, over5, flips, n = 0.0, 0, 0, 0, 3000
+    for _ in range(n):
+        q = rng.uniform(lo, -lo) * 0.5
+        quat = Rot.random(random_state=int(rng.integers(1 << 30))).as_quat()
+        pose = np.r_[rng.uniform([-0.1, -0.6, 0.05], [0.9, 0.6, 0.9]), quat]
+        ld0, c0, _ = oracle.query(q, pose, gjk_start=_abi.GJK_START_BULLET)
+        ld1, c1, _ = oracle.query(q, pose, gjk_start=_abi.GJK_START_GUIDED)
+        d = np.abs(ld0 - ld1)
+        worst = max(worst, float(d.max()))
+        over6 += int((d > 1e-6).sum())
+        over5 += int((d > 1e-5).sum())
+        flips += int(c0 != c1)
+    assert worst < 5e-4, worst
+    assert over6 < 0.03 * 5 * n and over5 < 0.005 * 5 * n, (over6, over5)
+    assert flips <= 3, flips

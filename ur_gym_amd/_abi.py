@@ -16,6 +16,7 @@ STATUS_GJK_ITER = 16
 
 OBS_DIMS = {ENV_ORI: (18, 6), ENV_OBS: (26, 3), ENV_DYN: (35, 6), ENV_STA: (29, 6)}  # (observation, goal) — core.py:241-247
 
+GJK_START_BULLET, GJK_START_GUIDED = 0, 1  # urgym_config.gjk_start (include/urgym.h)
 KEEP_SEED = 0xFFFFFFFFFFFFFFFF
 
 
@@ -28,7 +29,7 @@ class Config(C.Structure):
         ("check_collision", C.c_int32),
         ("max_reset_tries", C.c_int32),
         ("dyn_motion_steps", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("gjk_start", C.c_int32),
         ("action_scale", C.c_double),
         ("dt", C.c_double),
         ("distance_threshold", C.c_double),

@@ -388,6 +388,18 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
     D3 v0 = d3(0, 1, 0);
     int kind = 3, e = lane, lb = wv + 2;
     // builds the operands of one work item; returns false when there is nothing to run
+    // URGYM_GJK_START_GUIDED (include/urgym.h): first separating axis = unit vector from the other shape's centre to
+    // the mid point of the link's bounding capsule; same arithmetic as the oracle's guided_axis()
+    const bool guided = cfg.gjk_start == URGYM_GJK_START_GUIDED;
+    auto capsule_mid = [&](int link, const X3& TX) -> D3 {
+      const double* c = c_tab.capsule[link - 1];
+      return apply(TX, d3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5])));
+    };
+    auto guided_axis = [&](D3 mid, D3 centre) -> D3 {
+      const D3 d = mid - centre;
+      const double n2 = dot(d, d);
+      return n2 > 1e-12 ? d * (1.0 / sqrt(n2)) : d3(0, 1, 0);
+    };
     auto setup = [&](uint32_t item, bool cull) -> bool {
       e = item & 63;
       kind = (item >> 6) & 3;
@@ -435,19 +447,20 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
         sa = hull_desc(lb);
         sb = cyl_desc();
         store(pose_slot, rel(To, T));
-        v0 = rotT(To, d3(0, 1, 0));  // Bullet's pair detector starts from the world +Y axis
+        v0 = rotT(To, guided ? guided_axis(capsule_mid(lb, T), To.t) : d3(0, 1, 0));  // Bullet: the world +Y axis
       } else if (kind == Q_SELF) {
         sa = hull_desc(la);
         sb = hull_desc(lb);
         store(pose_slot, rel(T, TA));
-        v0 = rotT(T, d3(0, 1, 0));
+        v0 = rotT(T, guided ? guided_axis(capsule_mid(la, TA), capsule_mid(lb, T)) : d3(0, 1, 0));
       } else {
         const bool tbl = (kind == Q_TABLE);
         sa = hull_desc(lb);
         sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
-        T.t = T.t - d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+        const D3 centre = d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
+        v0 = guided ? guided_axis(capsule_mid(lb, T), centre) : d3(0, 1, 0);
+        T.t = T.t - centre;
         store(pose_slot, T);
-        v0 = d3(0, 1, 0);
       }
       return true;
     };
@@ -786,6 +799,7 @@ void fill_default(int env_kind, int num_envs, urgym_config* c) {
   c->auto_reset = 1;
   c->check_collision = 1;
   c->max_reset_tries = 4096;
+  c->gjk_start = URGYM_GJK_START_BULLET;
   c->dyn_motion_steps = 25;    // reach.py:735
   c->action_scale = M_PI * 0.1;
   c->dt = 20.0 / 500.0;        // pyb_setup.py:25,40
@@ -933,6 +947,8 @@ int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim) {
 int urgym_create(const urgym_config* cfg, int device, void** handle) {
   if (!cfg || !handle) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: null argument");
   if (cfg->env_kind < 0 || cfg->env_kind > 3 || cfg->num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad env_kind/num_envs");
+  if (cfg->gjk_start != URGYM_GJK_START_BULLET && cfg->gjk_start != URGYM_GJK_START_GUIDED)
+    return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad gjk_start");
   if (device < 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: this library has no CPU path; device must be a HIP ordinal >= 0");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
