@@ -1,0 +1,66 @@
+"""Diagnostic: per-wave phase timing of the step kernel from a -DURGYM_STAMPS build (ur_gym_amd/csrc/build/liburgym_stamps.so).
+
+    make -C ur_gym_amd/csrc stamps && python tools/phase_stamps.py [--env UR5DynReach-v1] [--num-envs 65536]
+
+Not part of the product: the stamped library is loaded in place of liburgym_hip.so only by this script."""
+import argparse, ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from ur_gym_amd import _native
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--env", default="UR5DynReach-v1")
+ap.add_argument("--num-envs", type=int, default=65536)
+ap.add_argument("--steps", type=int, default=12)
+args = ap.parse_args()
+_native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", "liburgym_stamps.so")
+from ur_gym_amd import make_vec
+
+env = make_vec(args.env, num_envs=args.num_envs, seed=5)
+env.reset(seed=5)
+gen = torch.Generator(device="cuda").manual_seed(5)
+for _ in range(args.steps):
+    env.step(torch.rand((args.num_envs, 6), device="cuda", generator=gen) * 2 - 1)
+torch.cuda.synchronize()
+groups = int(os.environ.get("URGYM_STEP_GROUPS", "0")) or (2 if (args.num_envs + 63) // 64 > 512 else 1)
+blocks = min(8192, (args.num_envs + 64 * groups - 1) // (64 * groups))
+W, S = 5, 12
+buf = np.zeros(blocks * W * S, dtype=np.uint64)
+lib = env.lib
+lib.urgym_debug_stamps.argtypes = [C.c_void_p, C.c_int]
+assert lib.urgym_debug_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+st = buf.reshape(blocks, W, S).astype(np.int64)
+t0 = st[:, :, 0].min(axis=1, keepdims=True)
+# s_memtime counts shader cycles, s_memrealtime 100 MHz: calibrate one against the other over the block lifetimes
+real = (st[:, :, 9] - st[:, :, 8]).astype(np.float64)
+cyc = (st[:, :, 7] - st[:, :, 0]).astype(np.float64)
+ghz = cyc.sum() / (real.sum() * 10.0) / 1e3 * 1e3 / 1e3
+print(f"in-kernel clock ~ {cyc.sum() / real.sum() / 10.0 / 100.0:.2f} GHz")
+tick = real.sum() / cyc.sum() / 100.0  # microseconds per shader cycle
+def us(x): return x * tick
+ph = {"start->P1 done": st[:, :, 1] - st[:, :, 0], "P1 barrier wait": st[:, :, 2] - st[:, :, 1], "first set-up": st[:, :, 3] - st[:, :, 2],
+      "GJK loop": st[:, :, 4] - st[:, :, 3], "loop barrier wait": st[:, :, 6] - st[:, :, 4], "P4": st[:, :, 7] - st[:, :, 6]}
+print(f"{args.env} N={args.num_envs} groups/block={groups} blocks={blocks}  (last step; mean over waves, microseconds)")
+for k, v in ph.items():
+    print(f"  {k:20s} mean {us(v.mean()):8.1f}  p50 {us(np.median(v)):8.1f}  max {us(v.max()):8.1f}")
+trips = st[:, :, 5] & 0xFFFFFFFF
+draws = st[:, :, 5] >> 32
+loop = (st[:, :, 4] - st[:, :, 3])
+print(f"  loop trips per wave: mean {trips.mean():.1f} max {trips.max()}   draws per wave: mean {draws.mean():.1f}")
+print(f"  time per loop trip: {us(loop.sum()) / trips.sum():.2f} us")
+blk = st[:, :, 7].max(axis=1) - st[:, :, 0].min(axis=1)
+print(f"  block lifetime: mean {us(blk.mean()):.1f} us, max {us(blk.max()):.1f} us; kernel span {us(st[:, :, 7].max() - st[:, :, 0].min()):.1f} us")
+
+occ = C.c_int(0)
+lib.urgym_debug_occupancy.argtypes = [C.POINTER(C.c_int)]
+print("  occupancy API: rc", lib.urgym_debug_occupancy(C.byref(occ)), "blocks per CU", occ.value)
+b0 = st[:, :, 8].min(axis=1); b1 = st[:, :, 9].max(axis=1)
+ts = np.linspace(b0.min(), b1.max(), 200)
+conc = [(int(((b0 <= t) & (b1 >= t)).sum())) for t in ts]
+print(f"  concurrent blocks over the kernel (100 MHz clock): max {max(conc)}, mean {np.mean(conc):.0f}; kernel span {(b1.max() - b0.min()) / 100.0:.1f} us")
+hw = st[:, 0, 10]; xcc = st[:, 0, 11]
+cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | ((xcc & 0xF) << 8)   # CU_ID | SE_ID | XCC
+mid = 0.5 * (b0.min() + b1.max())
+alive = (b0 <= mid) & (b1 >= mid)
+u, cnt = np.unique(cu[alive], return_counts=True)
+print(f"  at mid-kernel: {alive.sum()} blocks alive on {len(u)} distinct (xcc,se,cu) ids; blocks per id: max {cnt.max()}, mean {cnt.mean():.2f}")

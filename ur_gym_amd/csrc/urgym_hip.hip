@@ -32,10 +32,27 @@ using namespace urgym;
 
 namespace {
 
-constexpr int ENVS_PER_GROUP = 64;
-constexpr int WAVES = 5;
-constexpr int THREADS = ENVS_PER_GROUP * WAVES;
-constexpr int QUEUE_CAP = ENVS_PER_GROUP * 19;
+constexpr int GROUP = 64;       // env slots per wave-wide pass
+#ifndef URGYM_MAX_GROUPS
+#define URGYM_MAX_GROUPS 1
+#endif
+constexpr int MAX_GROUPS = URGYM_MAX_GROUPS;   // a workgroup serves 64 or 128 envs (KParams::groups)
+constexpr int MAX_ENVS = GROUP * MAX_GROUPS;
+#ifndef URGYM_WAVES
+#define URGYM_WAVES 4
+#endif
+constexpr int WAVES = URGYM_WAVES;  // waves per workgroup
+constexpr int THREADS = GROUP * WAVES;
+constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
+#ifndef URGYM_REFILL_MIN
+#define URGYM_REFILL_MIN 32
+#endif
+constexpr int REFILL_MIN = URGYM_REFILL_MIN;
+// bits of the per-env culling mask: table vs links 2..6, track vs links 2..6, the nine self pairs
+constexpr int PAIR_TABLE = 0, PAIR_TRACK = 5, PAIR_SELF = 10;
+__host__ __device__ constexpr int self_pair_bit(int la, int lb) {  // (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6)
+  return PAIR_SELF + (la == 1 ? 0 : (la == 2 ? 4 : 7)) + (lb - (la + 2));
+}
 
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2 };
 enum { Q_TABLE = 0, Q_TRACK = 1, Q_SELF = 2 };
@@ -65,6 +82,7 @@ struct KParams {
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
+  int groups;       // 64-env groups per workgroup: 1 or 2 (<= MAX_GROUPS)
 };
 
 __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
@@ -277,17 +295,34 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
   B.episode_id[n] = (int32_t)(episode + 1);
 }
 
+// Diagnostic build only (-DURGYM_STAMPS): per-wave s_memtime stamps of the step kernel's phases (tools/phase_stamps.py).
+// The stamps go to a buffer of their own; no output value depends on them.  Not compiled into the product.
+#ifdef URGYM_STAMPS
+constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 12;
+__device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
+#define STAMP(k, v)                                                                                         \
+  do {                                                                                                      \
+    if (MODE == MODE_STEP && lane == 0 && blockIdx.x < STAMP_BLOCKS)                                        \
+      g_stamps[((size_t)blockIdx.x * WAVES + wv) * STAMP_SLOTS + (k)] = (unsigned long long)(v);            \
+  } while (0)
+#define STAMP_TIME(k) STAMP(k, __builtin_amdgcn_s_memtime())
+#else
+#define STAMP(k, v) do {} while (0)
+#define STAMP_TIME(k) do {} while (0)
+#endif
+
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const float* __restrict__ actions) {
-  __shared__ double s_dist[WAVES][ENVS_PER_GROUP];
-  __shared__ double s_sc[12][ENVS_PER_GROUP];   // sin (0..5) and cos (6..11) of those joints: computed once, used by every FK
-  __shared__ double s_obst[7][ENVS_PER_GROUP];  // obstacle position + quaternion of the step (after its motion)
-  __shared__ uint32_t s_queue[QUEUE_CAP];
-  __shared__ int s_qcount, s_qhead;
-  __shared__ int s_coll[ENVS_PER_GROUP];
-  __shared__ int s_flags[ENVS_PER_GROUP];
-  __shared__ int s_env[ENVS_PER_GROUP];         // global env id of slot e, -1 = empty slot
-  __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];        // per-lane GJK operand: pose of shape A in B's frame (+ Bullet's m_lastW)
+__global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const float* __restrict__ actions) {
+  // per-env slots (E = 64 * P.groups envs per workgroup, sized for MAX_GROUPS) ...
+  __shared__ double s_dist[5][MAX_ENVS];
+  __shared__ double s_q[6][MAX_ENVS];      // joint vector of the step (after the action)
+  __shared__ double s_obst[7][MAX_ENVS];   // obstacle position + quaternion of the step (after its motion)
+  __shared__ uint32_t s_pairs[MAX_ENVS];   // culling survivors: one bit per table / track / self pair (PAIR_* below)
+  __shared__ int s_flags[MAX_ENVS];        // status bits | COLL_BIT
+  __shared__ int s_env[MAX_ENVS];          // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
+  __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
+  // ... and per-lane slots
+  __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
 
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
@@ -296,28 +331,37 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int OD = P.obs_dim, GD = P.goal_dim;
+  const int G = P.groups;        // 1 or 2 groups of 64 envs
+  const int E = GROUP * G;       // envs of this workgroup
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
+  constexpr int COLL_BIT = 1 << 30;
   const XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
-  static_assert(sizeof(float) * ENVS_PER_GROUP * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
+  static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
 
   int list_count = 0;
   if (MODE != MODE_STEP) {
     list_count = B.done_count[P.pp];
-    if (blockIdx.x * ENVS_PER_GROUP >= list_count) return;  // uniform for the whole group
+    if ((int)blockIdx.x * E >= list_count) return;  // uniform for the whole workgroup
   }
+  if (tid == 0) { s_ticket = THREADS; s_pending = 0; }
+  STAMP_TIME(0);
+  STAMP(8, __builtin_amdgcn_s_memrealtime());
+#ifdef URGYM_STAMPS
+  { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); STAMP(10, hw); STAMP(11, xcc); }
+#endif
+  __syncthreads();
 
-  // ---- P1 (wave 0, one lane per env slot): which env, joint update, obstacle motion -> LDS
-  if (wv == 0) {
-    const int idx = blockIdx.x * ENVS_PER_GROUP + lane;
+  // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
+  //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
+  if (wv < G) {
+    const int e = wv * GROUP + lane;
+    const int idx = blockIdx.x * E + e;
     int n = -1;
     if (MODE == MODE_STEP) n = idx < N ? idx : -1;
     else n = idx < list_count ? B.done_list[idx] : -1;
     int flags = 0;
     if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
-    s_flags[lane] = flags;
-    s_coll[lane] = 0;
-    if (lane == 0) { s_qcount = 0; s_qhead = 0; }
     double q[6] = {0, 0, 0, 0, 0, 0};
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
@@ -363,31 +407,61 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
         }
       }
     }
-    s_env[lane] = (n >= 0 && finite) ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
-    for (int i = 0; i < 6; i++) {
-      double sn, cs;
-      sincos(q[i], &sn, &cs);
-      s_sc[i][lane] = sn;
-      s_sc[6 + i][lane] = cs;
+    const bool live = (n >= 0 && finite);
+    s_env[e] = live ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
+    s_flags[e] = flags;
+    for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
+    s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
+    s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
+    if (HAS_OBST && !live)
+      for (int i = 0; i < 5; i++) s_dist[i][e] = (n >= 0) ? __builtin_nan("") : 1e30;
+    // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
+    uint32_t pairs = 0;
+    if (live && cfg.check_collision && MODE != MODE_RESET) {
+      const double lim = cfg.collision_margin + 1e-6;
+      X3 T = identity_x3();
+      D3 a0[3], a1[3];
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        double sn, cs;
+        sincos(q[k], &sn, &cs);
+        fk_joint(T, k, sn, cs);
+        const int link = k + 1;
+        const double* c = c_tab.capsule[k];
+        const D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
+        const double rb = c[6];
+        if (k < 3) { a0[k] = b0; a1[k] = b1; }
+        if (link >= 2) {
+          if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim) pairs |= 1u << (PAIR_TABLE + link - 2);
+          if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim) pairs |= 1u << (PAIR_TRACK + link - 2);
+        }
+        // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6)
+#pragma unroll
+        for (int A = 1; A <= 3; A++) {
+          if (A <= link - 2) {
+            if (segseg_dist(a0[A - 1], a1[A - 1], b0, b1) - c_tab.capsule[A - 1][6] - rb <= lim) pairs |= 1u << self_pair_bit(A, link);
+          }
+        }
+      }
     }
-    s_obst[0][lane] = opos[0]; s_obst[1][lane] = opos[1]; s_obst[2][lane] = opos[2];
-    s_obst[3][lane] = oq.x; s_obst[4][lane] = oq.y; s_obst[5][lane] = oq.z; s_obst[6][lane] = oq.w;
+    s_pairs[e] = pairs;
+    if (pairs) atomicAdd(&s_pending, __popc(pairs));
   }
+  STAMP_TIME(1);
   __syncthreads();
 
-  // ---- P2 + P3: all closest-distance work of the group goes through ONE inlined, resumable GJK body.
-  //   setup   : lane (env e, link L = wave + 2): float64 FK to link L, bounding-capsule culling of the table / track /
-  //             self pairs that involve L (pyb_setup.py:407-427; survivors -> LDS queue), pose of hull L in the obstacle
-  //             frame -> the lane's LDS slot
-  //   iterate : every lane advances its query by one GJK iteration per loop trip: first the exact distance
-  //             hull(L) <-> obstacle cylinder (pyb_setup.py:439-456, also the obstacle rule of check_collision); a lane
-  //             that is done takes the next queued (rare) pair — boolean "closer than the margin?" — so those pairs are
-  //             worked off in the shadow of the slowest obstacle queries instead of in extra, almost empty rounds
+  // ---- P2 + P3: all closest-distance work of the workgroup goes through ONE inlined, resumable GJK body, fed from a
+  //      work pool so that no lane waits for the slowest query of its wave:
+  //   obstacle tickets t in [0, 5E): exact distance hull(link 2 + t / E) <-> obstacle cylinder of env slot t % E
+  //             (pyb_setup.py:439-456; also the obstacle rule of check_collision).  The first 320 tickets are the lanes'
+  //             own (link uniform per wave), the rest (G = 2) is drawn from s_ticket as lanes finish.
+  //   pair bits: the culling survivors of P1, boolean "closer than the margin?" queries, claimed bit by bit once the
+  //             tickets are gone.
+  //   A lane advances its query by one GJK iteration per loop trip; a finished lane draws the next item.
   {
     ShapeDesc sa = hull_desc(1), sb = cyl_desc();
     D3 v0 = d3(0, 1, 0);
-    int kind = 3, e = lane, lb = wv + 2;
-    // builds the operands of one work item; returns false when there is nothing to run
+    int kind = 3, e = 0, lb = 2;
     // URGYM_GJK_START_GUIDED (include/urgym.h): first separating axis = unit vector from the other shape's centre to
     // the mid point of the link's bounding capsule; same arithmetic as the oracle's guided_axis()
     const bool guided = cfg.gjk_start == URGYM_GJK_START_GUIDED;
@@ -400,47 +474,22 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
       const double n2 = dot(d, d);
       return n2 > 1e-12 ? d * (1.0 / sqrt(n2)) : d3(0, 1, 0);
     };
-    auto setup = [&](uint32_t item, bool cull) -> bool {
-      e = item & 63;
-      kind = (item >> 6) & 3;
-      lb = (item >> 8) & 7;
-      const int la = (item >> 11) & 7;
+    // builds the operands of one work item (e | kind << 8 | lb << 10 | la << 13); false when there is nothing to run
+    auto setup = [&](uint32_t item) -> bool {
+      e = item & 255;
+      kind = (item >> 8) & 3;
+      lb = (item >> 10) & 7;
+      const int la = (item >> 13) & 7;
+      if (s_env[e] < 0) return false;
       X3 T = identity_x3(), TA = identity_x3();
-      // FK to link lb; the world capsules of links 1..3 (self-collision culling) are parked in the lane's LDS slot,
-      // which is free until the GJK operand is stored
 #pragma unroll 1
       for (int k = 0; k < lb; k++) {
-        fk_joint(T, k, s_sc[k][e], s_sc[6 + k][e]);
+        double sn, cs;
+        sincos(s_q[k][e], &sn, &cs);
+        fk_joint(T, k, sn, cs);
         if (k + 1 == la) TA = T;
-        if (k < 3 && cull) {
-          const double* c = c_tab.capsule[k];
-          const D3 c0 = apply(T, d3(c[0], c[1], c[2])), c1 = apply(T, d3(c[3], c[4], c[5]));
-          pose_slot.set(6 * k + 0, c0.x); pose_slot.set(6 * k + 1, c0.y); pose_slot.set(6 * k + 2, c0.z);
-          pose_slot.set(6 * k + 3, c1.x); pose_slot.set(6 * k + 4, c1.y); pose_slot.set(6 * k + 5, c1.z);
-        }
       }
       if (kind == 3) {
-        if (cull) {
-          const double* c = c_tab.capsule[lb - 1];
-          D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
-          const double rb = c[6];
-          const double lim = cfg.collision_margin + 1e-6;
-          if (seg_box_lower_bound(b0, b1, TABLE_CX, TABLE_CY, TABLE_CZ, TABLE_HX, TABLE_HY, TABLE_HZ) - rb <= lim)
-            s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TABLE << 6) | ((uint32_t)lb << 8);
-          if (seg_box_lower_bound(b0, b1, TRACK_CX, TRACK_CY, TRACK_CZ, TRACK_HX, TRACK_HY, TRACK_HZ) - rb <= lim)
-            s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_TRACK << 6) | ((uint32_t)lb << 8);
-          // self pairs (pyb_setup.py:417-427): (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6), filed under link B
-#pragma unroll 1
-          for (int A = 1; A <= 3 && A <= lb - 2; A++) {
-            const double ra = c_tab.capsule[A - 1][6];
-            const int o = 6 * (A - 1);
-            const D3 a0 = d3(pose_slot.at(o), pose_slot.at(o + 1), pose_slot.at(o + 2));
-            const D3 a1 = d3(pose_slot.at(o + 3), pose_slot.at(o + 4), pose_slot.at(o + 5));
-            if (segseg_dist(a0, a1, b0, b1) - ra - rb <= lim)
-              s_queue[atomicAdd(&s_qcount, 1)] = (uint32_t)e | (Q_SELF << 6) | ((uint32_t)lb << 8) | ((uint32_t)A << 11);
-          }
-        }
-        if (!HAS_OBST) return false;
         X3 To;
         quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
         To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
@@ -464,22 +513,51 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
       }
       return true;
     };
+    // claims one set bit of s_pairs (the caller holds a claim on s_pending, so one exists) and decodes it into an item
+    auto claim_pair = [&]() -> uint32_t {
+      int pe = tid & (E - 1);
+#pragma unroll 1
+      for (int trip = 0; trip < 2 * MAX_ENVS; trip++, pe = (pe + 1) & (E - 1)) {
+        uint32_t m = s_pairs[pe];
+        while (m) {
+          const int b = __ffs((int)m) - 1;
+          const uint32_t old = atomicAnd(&s_pairs[pe], ~(1u << b));
+          if (old & (1u << b)) {
+            if (b < PAIR_TRACK) return (uint32_t)pe | (Q_TABLE << 8) | ((uint32_t)(b - PAIR_TABLE + 2) << 10);
+            if (b < PAIR_SELF) return (uint32_t)pe | (Q_TRACK << 8) | ((uint32_t)(b - PAIR_TRACK + 2) << 10);
+            const int i = b - PAIR_SELF;  // (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6)
+            const int la = i < 4 ? 1 : (i < 7 ? 2 : 3);
+            const int l2 = i < 4 ? 3 + i : (i < 7 ? i : i - 2);
+            return (uint32_t)pe | (Q_SELF << 8) | ((uint32_t)l2 << 10) | ((uint32_t)la << 13);
+          }
+          m = old & ~(1u << b);
+        }
+      }
+      return NO_ITEM;  // unreachable while the claim count is right; bounded so that a wave can never spin here
+    };
     // Bullet margins of the pair and its early-out distance (margins + 0.02 + query threshold): get_link_distances
     // queries with distance=5.0 (pyb_setup.py:452), check_collision with 0.01 (pyb_setup.py:402-422).  Recomputed from
     // `kind` where needed: nothing constant-like stays live across the search (see DESIGN.md "toolchain hazard").
     auto margin_sum = [&]() -> double {
       return M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
     };
+    const int n_tickets = HAS_OBST ? 5 * E : 0;
+    auto ticket_item = [&](int t) -> uint32_t {
+      const int te = t & (E - 1), link = 2 + (G == 2 ? (t >> 7) : (t >> 6));
+      return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
+    };
 
     GjkRun run;
     bool busy = false;
-    if (s_env[lane] >= 0 && (HAS_OBST || (cfg.check_collision && MODE != MODE_RESET))) {
-      busy = setup((uint32_t)lane | (3u << 6) | ((uint32_t)(wv + 2) << 8), cfg.check_collision && MODE != MODE_RESET);
+    STAMP_TIME(2);
+    if (tid < n_tickets) {
+      busy = setup(ticket_item(tid));
       if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + 5.0);
     }
-    if (!busy && HAS_OBST) s_dist[wv][lane] = (s_env[lane] <= -2) ? __builtin_nan("") : 1e30;
-    __syncthreads();  // the queue of culling survivors is complete
+    STAMP_TIME(3);
+    int trips = 0, draws = 0;
     for (;;) {
+      trips++;
       if (busy) {
         gjk_iterate(run, P.graph, sa, pose_slot, sb);
         if (run.done) {
@@ -491,56 +569,67 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
             s_dist[lb - 2][e] = dist;
           } else {
             const bool hit = (run.info & GJK_PENETRATING) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
-            if (hit) atomicOr(&s_coll[e], 1);
+            if (hit) atomicOr(&s_flags[e], COLL_BIT);
           }
           busy = false;
         }
       }
-      if (!busy && s_qhead < s_qcount) {
-        const int it = atomicAdd(&s_qhead, 1);
-        if (it < s_qcount) {
-          busy = setup(s_queue[it], false);
-          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + cfg.collision_margin);
+      const bool more_tickets = s_ticket < n_tickets, more_pairs = s_pending > 0;  // wave-uniform reads
+      // drawing an item costs the whole wave a set-up (FK + operands) and a seed pass of the hill climb, so idle lanes
+      // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
+      const int idle_lanes = __popcll(__ballot(!busy));
+      if (!busy && (idle_lanes >= REFILL_MIN || idle_lanes == 64)) {
+        draws++;
+        uint32_t item = NO_ITEM;
+        if (more_tickets) {
+          const int t = atomicAdd(&s_ticket, 1);
+          if (t < n_tickets) item = ticket_item(t);
+        } else if (more_pairs) {
+          if (atomicSub(&s_pending, 1) > 0) item = claim_pair();
+        }
+        if (item != NO_ITEM) {
+          busy = setup(item);
+          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + (kind == 3 ? 5.0 : cfg.collision_margin));
         }
       }
-      if (__ballot(busy) == 0ull) break;  // this wave has nothing left (other waves keep pulling from the queue)
+      if (__ballot(busy) == 0ull && !more_tickets && !more_pairs) break;  // nothing left for this wave to draw
     }
+    STAMP_TIME(4);
+    STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
   }
   __syncthreads();
+  STAMP_TIME(6);
 
   // ---- P4: one lane per env re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
-  if (wv == WAVES - 1 && s_env[lane] != -1) {
-    const int n = s_env[lane] >= 0 ? s_env[lane] : -2 - s_env[lane];
-    // the joint vector again, by the very arithmetic of P1 (cheaper than 3 KB of LDS)
+  const int pe = (wv - (WAVES - G)) * GROUP + lane;  // env slot of this lane in P4 (waves WAVES-G .. WAVES-1)
+  if (wv >= WAVES - G && s_env[pe] != -1) {
+    const int n = s_env[pe] >= 0 ? s_env[pe] : -2 - s_env[pe];
     double q[6];
-    for (int i = 0; i < 6; i++) {
-      q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
-      if (MODE == MODE_STEP) {
-        float a = actions[(size_t)n * 6 + i];
-        a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
-        q[i] += (double)__fmul_rn(__fmul_rn(a, 3.14159274101257324f), 0.1f);
-      }
-    }
+    for (int i = 0; i < 6; i++) q[i] = s_q[i][pe];
     X3 TE = identity_x3();
 #pragma unroll 1
-    for (int k = 0; k < 6; k++) fk_joint(TE, k, s_sc[k][lane], s_sc[6 + k][lane]);
-    double opos[3] = {s_obst[0][lane], s_obst[1][lane], s_obst[2][lane]};
-    Q4 oq{s_obst[3][lane], s_obst[4][lane], s_obst[5][lane], s_obst[6][lane]};
+    for (int k = 0; k < 6; k++) {
+      double sn, cs;
+      sincos(q[k], &sn, &cs);
+      fk_joint(TE, k, sn, cs);
+    }
+    double opos[3] = {s_obst[0][pe], s_obst[1][pe], s_obst[2][pe]};
+    Q4 oq{s_obst[3][pe], s_obst[4][pe], s_obst[5][pe], s_obst[6][pe]};
     const int step_count = B.step_count[n];
     Q4 eq = rot_to_quat(TE.r);
     double er, ep, ey;
     rpy_from_quat(eq, er, ep, ey);
-    float* row = &s_out[lane * 47];
+    float* row = &s_out[pe * 47];
     float ach[6];
     ach[0] = (float)TE.t.x; ach[1] = (float)TE.t.y; ach[2] = (float)TE.t.z;
     ach[3] = (float)er; ach[4] = (float)ep; ach[5] = (float)ey;
     double goal[6];
     for (int i = 0; i < 6; i++) goal[i] = SOA(B.goal, i, n, N);
     double ld_old[5] = {0, 0, 0, 0, 0}, ld_new[5] = {0, 0, 0, 0, 0};
-    bool coll = s_coll[lane] != 0;
+    bool coll = (s_flags[pe] & COLL_BIT) != 0;
     if (HAS_OBST) {
       for (int i = 0; i < 5; i++) {
-        ld_new[i] = s_dist[i][lane];
+        ld_new[i] = s_dist[i][pe];
         if (MODE == MODE_STEP) ld_old[i] = SOA(B.link_dist, i, n, N);
         if (cfg.check_collision && ld_new[i] <= cfg.collision_margin) coll = true;
       }
@@ -598,7 +687,7 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
       th = angular_distance(a3, goal + 3);
       succ = (d < cfg.distance_threshold) && (th < cfg.ori_threshold);
     }
-    int flags = s_flags[lane];
+    int flags = s_flags[pe] & ~COLL_BIT;
     if (MODE == MODE_STEP) {
       bool terminated = succ || coll;                 // core.py:313
       bool info_success = terminated ? !coll : false; // core.py:315
@@ -679,12 +768,14 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
     }
     if (flags) atomicOr(&B.status[n], flags);
   }
+  STAMP_TIME(7);
+  STAMP(9, __builtin_amdgcn_s_memrealtime());
   __syncthreads();
 
   // ---- write-back of the observation rows staged in LDS (coalesced for STEP: the group's rows are contiguous)
   if (MODE == MODE_STEP) {
-    const int base = blockIdx.x * ENVS_PER_GROUP;
-    const int cnt = min(ENVS_PER_GROUP, N - base);
+    const int base = blockIdx.x * E;
+    const int cnt = min(E, N - base);
     for (int i = tid; i < cnt * OD; i += THREADS) B.observation[(size_t)base * OD + i] = s_out[(i / OD) * 47 + (i % OD)];
     for (int i = tid; i < cnt * GD; i += THREADS) {
       B.achieved_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + (i % GD)];
@@ -692,7 +783,7 @@ __global__ void __launch_bounds__(THREADS, 3) env_kernel(const KParams P, const 
     }
     if (blockIdx.x == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
   } else {
-    const int cnt = min(ENVS_PER_GROUP, list_count - (int)blockIdx.x * ENVS_PER_GROUP);
+    const int cnt = min(E, list_count - (int)blockIdx.x * E);
     for (int i = tid; i < cnt * OD; i += THREADS) {
       const int e = i / OD;
       const int se = s_env[e];
@@ -768,6 +859,7 @@ struct Handle {
   SeedRec* d_seeds = nullptr;
   uint64_t seed = 0;
   int pp = 0;
+  int step_groups = 1;  // 64-env groups per workgroup of the step kernel (see urgym_create)
   char err[512] = {0};
   // timing
   bool timing = false;
@@ -852,12 +944,16 @@ KParams make_params(Handle* h, int copy_final) {
   P.seed_hi = (uint32_t)(h->seed >> 32);
   P.pp = h->pp;
   P.copy_final = copy_final;
+  P.groups = 1;
   return P;
 }
 
 template <int MODE>
-void launch_mode(Handle* h, const KParams& P, const float* actions, int groups, hipStream_t s) {
-  dim3 grid(groups), block(THREADS);
+void launch_mode(Handle* h, KParams P, const float* actions, int groups_per_block, hipStream_t s) {
+  if (groups_per_block < 1 || groups_per_block > MAX_GROUPS) groups_per_block = 1;  // the kernel's LDS is sized for MAX_GROUPS
+  P.groups = groups_per_block;
+  const int envs = GROUP * groups_per_block;
+  dim3 grid((h->cfg.num_envs + envs - 1) / envs), block(THREADS);
   switch (h->cfg.env_kind) {
     case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
     case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE>), grid, block, 0, s, P, actions); break;
@@ -893,15 +989,13 @@ int check_bound(Handle* h) {
 }
 
 int do_step(Handle* h, const float* actions, hipStream_t s) {
-  const int N = h->cfg.num_envs;
-  const int groups = (N + ENVS_PER_GROUP - 1) / ENVS_PER_GROUP;
   KParams P = make_params(h, 1);
   int slot = time_begin(h, 0, s);
-  launch_mode<MODE_STEP>(h, P, actions, groups, s);
+  launch_mode<MODE_STEP>(h, P, actions, h->step_groups, s);
   time_end(h, slot, s);
   if (h->cfg.auto_reset) {
     slot = time_begin(h, 1, s);
-    launch_mode<MODE_RESET>(h, P, nullptr, groups, s);
+    launch_mode<MODE_RESET>(h, P, nullptr, 1, s);  // few envs per step: 64-env workgroups spread them over more CUs
     time_end(h, slot, s);
   }
   h->pp ^= 1;
@@ -911,14 +1005,13 @@ int do_step(Handle* h, const float* actions, hipStream_t s) {
 
 int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
   const int N = h->cfg.num_envs;
-  const int groups = (N + ENVS_PER_GROUP - 1) / ENVS_PER_GROUP;
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count + h->pp, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(build_list_kernel, dim3((N + 255) / 256), dim3(256), 0, s, mask, N, h->buf.done_list, h->buf.done_count + h->pp);
   KParams P = make_params(h, 0);
   if (mode == MODE_RESET)
-    launch_mode<MODE_RESET>(h, P, nullptr, groups, s);
+    launch_mode<MODE_RESET>(h, P, nullptr, h->step_groups, s);
   else
-    launch_mode<MODE_REFRESH>(h, P, nullptr, groups, s);
+    launch_mode<MODE_REFRESH>(h, P, nullptr, h->step_groups, s);
   // leave the consumed counter zeroed so the next step can append to either slot
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count, 0, 2 * sizeof(int32_t), s));
   HIP_TRY(h, hipGetLastError());
@@ -981,6 +1074,19 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     if (h->d_seeds) hipFree(h->d_seeds);
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
+  }
+  // Envs per step workgroup: 64 while that fills the chip in one round of resident workgroups (2 per CU), otherwise 128,
+  // where a finished lane draws a second obstacle query instead of idling behind the slowest query of its wave
+  // (DESIGN.md "work pool").  URGYM_STEP_GROUPS=1|2 overrides the choice (tuning / tests).
+  {
+    int cus = 256;
+    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    const int blocks64 = (cfg->num_envs + GROUP - 1) / GROUP;
+    h->step_groups = (MAX_GROUPS >= 2 && blocks64 > 2 * cus) ? 2 : 1;
+    if (const char* ov = getenv("URGYM_STEP_GROUPS")) {
+      const int g = atoi(ov);
+      if (g >= 1 && g <= MAX_GROUPS) h->step_groups = g;
+    }
   }
   *handle = h;
   return URGYM_OK;
@@ -1094,6 +1200,15 @@ int urgym_query_timing(void* handle, double* step_us, double* reset_us, int* lau
   h->ev_used = 0;
   return URGYM_OK;
 }
+
+#ifdef URGYM_STAMPS
+int urgym_debug_occupancy(int* blocks_per_cu) {
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP>, THREADS, 0);
+}
+int urgym_debug_stamps(unsigned long long* out, int count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 const char* urgym_last_error(void* handle) {
   Handle* h = (Handle*)handle;
