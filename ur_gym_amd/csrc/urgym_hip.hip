@@ -82,7 +82,7 @@ struct KParams {
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
-  int groups;       // 64-env groups per workgroup: 1 or 2 (<= MAX_GROUPS)
+  int envs, envs_log2;  // envs per workgroup: a power of two, 8 .. MAX_ENVS (64 for the step kernel)
 };
 
 __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
@@ -218,6 +218,30 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
   uint32_t episode = (uint32_t)B.episode_id[n];
   double goal[6] = {0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
   for (int attempt = 0;; attempt++) {
+    if (KIND == URGYM_ENV_DYN) {
+      // Dyn rejects ~83 % of its draws on the start->end travel alone (reach.py:675).  Skip ahead to the next draw that
+      // passes that test before doing anything expensive: only the two positions are needed (Philox blocks 1..3), and
+      // the lanes of a wave then meet at the target-clearance query below a handful of times instead of ~30.  The
+      // accepted draw is the same one the sequential loop accepts: every test is a pure function of (env, episode, attempt).
+#pragma unroll 1
+      for (; attempt + 1 < cfg.max_reset_tries; attempt++) {
+        uint32_t o1[4], o2[4], o3[4];
+        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 1u, o1);
+        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 2u, o2);
+        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 3u, o3);
+        const double us[3] = {u01(o1[1]), u01(o1[2]), u01(o1[3])};   // u[5], u[6], u[7]
+        const double ue[3] = {u01(o2[3]), u01(o3[0]), u01(o3[1])};   // u[11], u[12], u[13]
+        double d2 = 0.0, dd[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          const double a = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * us[i];
+          const double b = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * ue[i];
+          dd[i] = b - a;
+        }
+        d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+        if (!(sqrt(d2) < cfg.min_travel)) break;
+      }
+    }
     double u[20];
 #pragma unroll
     for (int blk = 0; blk < 5; blk++) {
@@ -313,7 +337,7 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 
 template <int KIND, int MODE>
 __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const float* __restrict__ actions) {
-  // per-env slots (E = 64 * P.groups envs per workgroup, sized for MAX_GROUPS) ...
+  // per-env slots (E = P.envs envs per workgroup, a power of two <= MAX_ENVS) ...
   __shared__ double s_dist[5][MAX_ENVS];
   __shared__ double s_q[6][MAX_ENVS];      // joint vector of the step (after the action)
   __shared__ double s_obst[7][MAX_ENVS];   // obstacle position + quaternion of the step (after its motion)
@@ -331,8 +355,9 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int OD = P.obs_dim, GD = P.goal_dim;
-  const int G = P.groups;        // 1 or 2 groups of 64 envs
-  const int E = GROUP * G;       // envs of this workgroup
+  const int E = P.envs;                      // envs of this workgroup: a power of two, 8 .. MAX_ENVS
+  const int ESH = P.envs_log2;
+  const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
   const XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
@@ -358,8 +383,10 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
     const int e = wv * GROUP + lane;
     const int idx = blockIdx.x * E + e;
     int n = -1;
-    if (MODE == MODE_STEP) n = idx < N ? idx : -1;
-    else n = idx < list_count ? B.done_list[idx] : -1;
+    if (e < E) {
+      if (MODE == MODE_STEP) n = idx < N ? idx : -1;
+      else n = idx < list_count ? B.done_list[idx] : -1;
+    }
     int flags = 0;
     if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
     double q[6] = {0, 0, 0, 0, 0, 0};
@@ -543,7 +570,7 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
     };
     const int n_tickets = HAS_OBST ? 5 * E : 0;
     auto ticket_item = [&](int t) -> uint32_t {
-      const int te = t & (E - 1), link = 2 + (G == 2 ? (t >> 7) : (t >> 6));
+      const int te = t & (E - 1), link = 2 + (t >> ESH);
       return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
     };
 
@@ -860,6 +887,7 @@ struct Handle {
   uint64_t seed = 0;
   int pp = 0;
   int step_groups = 1;  // 64-env groups per workgroup of the step kernel (see urgym_create)
+  int reset_envs = 8;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
   char err[512] = {0};
   // timing
   bool timing = false;
@@ -944,15 +972,18 @@ KParams make_params(Handle* h, int copy_final) {
   P.seed_hi = (uint32_t)(h->seed >> 32);
   P.pp = h->pp;
   P.copy_final = copy_final;
-  P.groups = 1;
+  P.envs = GROUP;
+  P.envs_log2 = 6;
   return P;
 }
 
 template <int MODE>
-void launch_mode(Handle* h, KParams P, const float* actions, int groups_per_block, hipStream_t s) {
-  if (groups_per_block < 1 || groups_per_block > MAX_GROUPS) groups_per_block = 1;  // the kernel's LDS is sized for MAX_GROUPS
-  P.groups = groups_per_block;
-  const int envs = GROUP * groups_per_block;
+void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s) {
+  int lg = 3;
+  while ((1 << lg) < envs && (1 << lg) < MAX_ENVS) lg++;   // power of two in [8, MAX_ENVS]: the kernel's LDS is sized for MAX_ENVS
+  envs = 1 << lg;
+  P.envs = envs;
+  P.envs_log2 = lg;
   dim3 grid((h->cfg.num_envs + envs - 1) / envs), block(THREADS);
   switch (h->cfg.env_kind) {
     case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
@@ -991,11 +1022,11 @@ int check_bound(Handle* h) {
 int do_step(Handle* h, const float* actions, hipStream_t s) {
   KParams P = make_params(h, 1);
   int slot = time_begin(h, 0, s);
-  launch_mode<MODE_STEP>(h, P, actions, h->step_groups, s);
+  launch_mode<MODE_STEP>(h, P, actions, GROUP * h->step_groups, s);
   time_end(h, slot, s);
   if (h->cfg.auto_reset) {
     slot = time_begin(h, 1, s);
-    launch_mode<MODE_RESET>(h, P, nullptr, 1, s);  // few envs per step: 64-env workgroups spread them over more CUs
+    launch_mode<MODE_RESET>(h, P, nullptr, h->reset_envs, s);  // ~1 % of the envs per step: small workgroups, many CUs
     time_end(h, slot, s);
   }
   h->pp ^= 1;
@@ -1009,9 +1040,9 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
   hipLaunchKernelGGL(build_list_kernel, dim3((N + 255) / 256), dim3(256), 0, s, mask, N, h->buf.done_list, h->buf.done_count + h->pp);
   KParams P = make_params(h, 0);
   if (mode == MODE_RESET)
-    launch_mode<MODE_RESET>(h, P, nullptr, h->step_groups, s);
+    launch_mode<MODE_RESET>(h, P, nullptr, GROUP * h->step_groups, s);
   else
-    launch_mode<MODE_REFRESH>(h, P, nullptr, h->step_groups, s);
+    launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP * h->step_groups, s);
   // leave the consumed counter zeroed so the next step can append to either slot
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count, 0, 2 * sizeof(int32_t), s));
   HIP_TRY(h, hipGetLastError());
@@ -1083,6 +1114,10 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     const int blocks64 = (cfg->num_envs + GROUP - 1) / GROUP;
     h->step_groups = (MAX_GROUPS >= 2 && blocks64 > 2 * cus) ? 2 : 1;
+    if (const char* ov = getenv("URGYM_RESET_ENVS")) {
+      const int r = atoi(ov);
+      if (r >= 8 && r <= MAX_ENVS) h->reset_envs = r;
+    }
     if (const char* ov = getenv("URGYM_STEP_GROUPS")) {
       const int g = atoi(ov);
       if (g >= 1 && g <= MAX_GROUPS) h->step_groups = g;
