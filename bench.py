@@ -29,7 +29,7 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418, "UR5StaReach-v1": 370}  # SURVEY.md §8(d); Sta = Dyn without the velocity slots
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command
 
 
 def measured_traffic(env_id, n):
@@ -172,12 +172,12 @@ def main():
                        "gjk_start": args.gjk_start},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.env, n),
-                         "traffic_source": "profiles/r1/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
+                         "traffic_source": "profiles/r1_final/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": algo,
                          "kernel": "env_kernel<Dyn,STEP>" if args.env == "UR5DynReach-v1" else "env_kernel<STEP>",
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
-                         "note": "the kernel is VALU/LDS-bound in the GJK distance queries, not HBM-bound (DESIGN.md)"},
+                         "note": "bound by the dependent float64 chain of the GJK iterations (resident waves, then VALU issue), not by HBM (DESIGN.md section 4)"},
             "anomalous_envs": anomalies,
             "episodes_started": episodes,
         }

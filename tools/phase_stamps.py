@@ -12,7 +12,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--env", default="UR5DynReach-v1")
 ap.add_argument("--num-envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--envs-per-block", type=int, default=64, help="forces URGYM_STEP_ENVS so that the stamp layout is known")
 args = ap.parse_args()
+os.environ["URGYM_STEP_ENVS"] = str(args.envs_per_block)
 _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", "liburgym_stamps.so")
 from ur_gym_amd import make_vec
 
@@ -22,9 +24,9 @@ gen = torch.Generator(device="cuda").manual_seed(5)
 for _ in range(args.steps):
     env.step(torch.rand((args.num_envs, 6), device="cuda", generator=gen) * 2 - 1)
 torch.cuda.synchronize()
-groups = int(os.environ.get("URGYM_STEP_GROUPS", "0")) or (2 if (args.num_envs + 63) // 64 > 512 else 1)
-blocks = min(8192, (args.num_envs + 64 * groups - 1) // (64 * groups))
-W, S = 5, 12
+groups = args.envs_per_block
+blocks = min(8192, (args.num_envs + groups - 1) // groups)
+W, S = int(os.environ.get("URGYM_WAVES", "4")), 12
 buf = np.zeros(blocks * W * S, dtype=np.uint64)
 lib = env.lib
 lib.urgym_debug_stamps.argtypes = [C.c_void_p, C.c_int]
@@ -40,7 +42,7 @@ tick = real.sum() / cyc.sum() / 100.0  # microseconds per shader cycle
 def us(x): return x * tick
 ph = {"start->P1 done": st[:, :, 1] - st[:, :, 0], "P1 barrier wait": st[:, :, 2] - st[:, :, 1], "first set-up": st[:, :, 3] - st[:, :, 2],
       "GJK loop": st[:, :, 4] - st[:, :, 3], "loop barrier wait": st[:, :, 6] - st[:, :, 4], "P4": st[:, :, 7] - st[:, :, 6]}
-print(f"{args.env} N={args.num_envs} groups/block={groups} blocks={blocks}  (last step; mean over waves, microseconds)")
+print(f"{args.env} N={args.num_envs} envs/block={groups} blocks={blocks}  (last step; mean over waves, microseconds)")
 for k, v in ph.items():
     print(f"  {k:20s} mean {us(v.mean()):8.1f}  p50 {us(np.median(v)):8.1f}  max {us(v.max()):8.1f}")
 trips = st[:, :, 5] & 0xFFFFFFFF
@@ -58,6 +60,8 @@ b0 = st[:, :, 8].min(axis=1); b1 = st[:, :, 9].max(axis=1)
 ts = np.linspace(b0.min(), b1.max(), 200)
 conc = [(int(((b0 <= t) & (b1 >= t)).sum())) for t in ts]
 print(f"  concurrent blocks over the kernel (100 MHz clock): max {max(conc)}, mean {np.mean(conc):.0f}; kernel span {(b1.max() - b0.min()) / 100.0:.1f} us")
+print("  concurrency timeline (20 bins):", [conc[i] for i in range(5, 200, 10)])
+print(f"  first block start spread: {(b0.max() - b0.min()) / 100.0:.1f} us; sum of block lifetimes / span = {((b1 - b0).sum()) / (b1.max() - b0.min()):.1f} blocks on average")
 hw = st[:, 0, 10]; xcc = st[:, 0, 11]
 cu = ((hw >> 8) & 0xF) | (((hw >> 13) & 0x7) << 4) | ((xcc & 0xF) << 8)   # CU_ID | SE_ID | XCC
 mid = 0.5 * (b0.min() + b1.max())

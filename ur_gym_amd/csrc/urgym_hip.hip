@@ -33,11 +33,10 @@ using namespace urgym;
 namespace {
 
 constexpr int GROUP = 64;       // env slots per wave-wide pass
-#ifndef URGYM_MAX_GROUPS
-#define URGYM_MAX_GROUPS 1
+#ifndef URGYM_MAX_ENVS
+#define URGYM_MAX_ENVS 64
 #endif
-constexpr int MAX_GROUPS = URGYM_MAX_GROUPS;   // a workgroup serves 64 or 128 envs (KParams::groups)
-constexpr int MAX_ENVS = GROUP * MAX_GROUPS;
+constexpr int MAX_ENVS = URGYM_MAX_ENVS;   // most envs one workgroup serves (KParams::envs); bounded by the 53 KB LDS budget of STEP
 #ifndef URGYM_WAVES
 #define URGYM_WAVES 4
 #endif
@@ -82,7 +81,7 @@ struct KParams {
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
-  int envs, envs_log2;  // envs per workgroup: a power of two, 8 .. MAX_ENVS (64 for the step kernel)
+  int envs;         // envs per workgroup, 1 .. MAX_ENVS (chosen per launch: see urgym_create / do_step)
 };
 
 __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
@@ -319,6 +318,51 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
   B.episode_id[n] = (int32_t)(episode + 1);
 }
 
+// Joint k of env n for this launch: STEP = stored joint + float32(float32(clip(a) * pi32) * 0.1f) (UR5.py:273-279, 314);
+// RESET = the neutral pose (UR5.py:327-332); REFRESH = the stored joint.  A pure function of global memory that the
+// launch does not modify before its last barrier, so any lane may re-derive it instead of keeping it in LDS.
+template <int MODE>
+__device__ __forceinline__ double joint_of_step(const KParams& P, const float* __restrict__ actions, int n, int k) {
+  if (MODE == MODE_RESET) return P.cfg.neutral_q[k];
+  double q = P.buf.q[(size_t)k * P.cfg.num_envs + n];
+  if (MODE == MODE_STEP) {
+    float a = actions[(size_t)n * 6 + k];
+    a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);   // np.clip: a NaN action stays NaN (UR5.py:275)
+    float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
+    float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
+    q += (double)t2;
+  }
+  return q;
+}
+
+// Obstacle pose of env n during a STEP launch: the stored pose advanced by this step's motion (sim.step, pyb_setup.py:52-55).
+template <int KIND>
+__device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double opos[3], Q4& oq) {
+  const urgym_config& cfg = P.cfg;
+  const urgym_buffers& B = P.buf;
+  const int N = cfg.num_envs;
+  for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
+  oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
+  if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
+    double ovel[6];
+    for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
+    integrate_obstacle(opos, oq, ovel, cfg.dt);
+  }
+  if (KIND == URGYM_ENV_STA) {
+    // core.py:307-308 + ReachSta.set_velocity (reach.py:518-541): only when obstacle_end is not all-zero; the full
+    // start->end twist (time_duration = 1) while the obstacle is farther than 0.05 from its end position
+    double st[6], en[6];
+    bool moving = false;
+    for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); moving = moving || en[i] != 0.0; }
+    if (moving) {
+      const double dx = en[0] - opos[0], dy = en[1] - opos[1], dz = en[2] - opos[2];
+      double ovel[6] = {0, 0, 0, 0, 0, 0};
+      if (sqrt(dx * dx + dy * dy + dz * dz) > 0.05) dyn_velocity(st, en, 1.0, ovel);
+      integrate_obstacle(opos, oq, ovel, cfg.dt);
+    }
+  }
+}
+
 // Diagnostic build only (-DURGYM_STAMPS): per-wave s_memtime stamps of the step kernel's phases (tools/phase_stamps.py).
 // The stamps go to a buffer of their own; no output value depends on them.  Not compiled into the product.
 #ifdef URGYM_STAMPS
@@ -336,11 +380,16 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #endif
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const float* __restrict__ actions) {
-  // per-env slots (E = P.envs envs per workgroup, a power of two <= MAX_ENVS) ...
+__global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
+  // per-env slots (E = P.envs envs per workgroup, <= MAX_ENVS) ...
   __shared__ double s_dist[5][MAX_ENVS];
-  __shared__ double s_q[6][MAX_ENVS];      // joint vector of the step (after the action)
-  __shared__ double s_obst[7][MAX_ENVS];   // obstacle position + quaternion of the step (after its motion)
+  // STEP launches re-derive the joints and the obstacle pose from global memory wherever they are needed (joint_of_step,
+  // obstacle_of_step): 6.5 KB less LDS, which is what lets a third workgroup stay resident on the CU.  RESET / REFRESH
+  // launches hand them from the sampling lane to the query lanes through LDS (global memory written by this launch is
+  // not safely readable through the CU's L1).
+  constexpr bool LDS_STATE = (MODE != MODE_STEP);
+  __shared__ double s_q[LDS_STATE ? 6 : 1][LDS_STATE ? MAX_ENVS : 1];      // joint vector
+  __shared__ double s_obst[LDS_STATE ? 7 : 1][LDS_STATE ? MAX_ENVS : 1];   // obstacle position + quaternion
   __shared__ uint32_t s_pairs[MAX_ENVS];   // culling survivors: one bit per table / track / self pair (PAIR_* below)
   __shared__ int s_flags[MAX_ENVS];        // status bits | COLL_BIT
   __shared__ int s_env[MAX_ENVS];          // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
@@ -355,8 +404,7 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int OD = P.obs_dim, GD = P.goal_dim;
-  const int E = P.envs;                      // envs of this workgroup: a power of two, 8 .. MAX_ENVS
-  const int ESH = P.envs_log2;
+  const int E = P.envs;                      // envs of this workgroup, 1 .. MAX_ENVS
   const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
@@ -379,14 +427,12 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
 
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
-  if (wv < G) {
-    const int e = wv * GROUP + lane;
+  if (tid < E) {
+    const int e = tid;
     const int idx = blockIdx.x * E + e;
     int n = -1;
-    if (e < E) {
-      if (MODE == MODE_STEP) n = idx < N ? idx : -1;
-      else n = idx < list_count ? B.done_list[idx] : -1;
-    }
+    if (MODE == MODE_STEP) n = idx < N ? idx : -1;
+    else n = idx < list_count ? B.done_list[idx] : -1;
     int flags = 0;
     if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
     double q[6] = {0, 0, 0, 0, 0, 0};
@@ -394,52 +440,22 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
     Q4 oq{0, 0, 0, 1};
     bool finite = true;
     if (n >= 0) {
-      for (int i = 0; i < 6; i++) q[i] = (MODE == MODE_RESET) ? cfg.neutral_q[i] : SOA(B.q, i, n, N);
-      if (MODE == MODE_STEP) {
-        for (int i = 0; i < 6; i++) {
-          float a = actions[(size_t)n * 6 + i];
-          a = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);   // np.clip: a NaN action stays NaN (UR5.py:275)
-          float t1 = __fmul_rn(a, 3.14159274101257324f);  // float32(action * np.pi)   (UR5.py:276)
-          float t2 = __fmul_rn(t1, 0.1f);                  // float32(... * 0.1)         (UR5.py:314)
-          q[i] += (double)t2;
-        }
-      }
+      for (int i = 0; i < 6; i++) q[i] = joint_of_step<MODE>(P, actions, n, i);
       for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
-      if (HAS_OBST) {
-        if (MODE == MODE_STEP) {
-          for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
-          oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
-          if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
-            double ovel[6];
-            for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
-            integrate_obstacle(opos, oq, ovel, cfg.dt);
-          }
-          if (KIND == URGYM_ENV_STA) {
-            // core.py:307-308 + ReachSta.set_velocity (reach.py:518-541): only when obstacle_end is not all-zero; the full
-            // start->end twist (time_duration = 1) while the obstacle is farther than 0.05 from its end position
-            double st[6], en[6];
-            bool moving = false;
-            for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); moving = moving || en[i] != 0.0; }
-            if (moving) {
-              const double dx = en[0] - opos[0], dy = en[1] - opos[1], dz = en[2] - opos[2];
-              double ovel[6] = {0, 0, 0, 0, 0, 0};
-              if (sqrt(dx * dx + dy * dy + dz * dz) > 0.05) dyn_velocity(st, en, 1.0, ovel);
-              integrate_obstacle(opos, oq, ovel, cfg.dt);
-            }
-          }
-        } else {
-          // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
-          for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
-          oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
-        }
+      if (HAS_OBST && LDS_STATE) {
+        // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
+        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
+        oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
       }
     }
     const bool live = (n >= 0 && finite);
     s_env[e] = live ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
     s_flags[e] = flags;
-    for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
-    s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
-    s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
+    if (LDS_STATE) {
+      for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
+      s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
+      s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
+    }
     if (HAS_OBST && !live)
       for (int i = 0; i < 5; i++) s_dist[i][e] = (n >= 0) ? __builtin_nan("") : 1e30;
     // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
@@ -507,19 +523,28 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
       kind = (item >> 8) & 3;
       lb = (item >> 10) & 7;
       const int la = (item >> 13) & 7;
-      if (s_env[e] < 0) return false;
+      const int n = s_env[e];
+      if (n < 0) return false;
       X3 T = identity_x3(), TA = identity_x3();
 #pragma unroll 1
       for (int k = 0; k < lb; k++) {
         double sn, cs;
-        sincos(s_q[k][e], &sn, &cs);
+        sincos(LDS_STATE ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
         fk_joint(T, k, sn, cs);
         if (k + 1 == la) TA = T;
       }
       if (kind == 3) {
         X3 To;
-        quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
-        To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
+        if (LDS_STATE) {
+          quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
+          To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
+        } else {
+          double op[3];
+          Q4 oqs;
+          obstacle_of_step<KIND>(P, n, op, oqs);
+          quat_to_rot(oqs, To.r);
+          To.t = d3(op[0], op[1], op[2]);
+        }
         sa = hull_desc(lb);
         sb = cyl_desc();
         store(pose_slot, rel(To, T));
@@ -542,9 +567,9 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
     };
     // claims one set bit of s_pairs (the caller holds a claim on s_pending, so one exists) and decodes it into an item
     auto claim_pair = [&]() -> uint32_t {
-      int pe = tid & (E - 1);
+      int pe = tid % E;
 #pragma unroll 1
-      for (int trip = 0; trip < 2 * MAX_ENVS; trip++, pe = (pe + 1) & (E - 1)) {
+      for (int trip = 0; trip < 2 * MAX_ENVS; trip++, pe = (pe + 1 == E ? 0 : pe + 1)) {
         uint32_t m = s_pairs[pe];
         while (m) {
           const int b = __ffs((int)m) - 1;
@@ -570,7 +595,7 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
     };
     const int n_tickets = HAS_OBST ? 5 * E : 0;
     auto ticket_item = [&](int t) -> uint32_t {
-      const int te = t & (E - 1), link = 2 + (t >> ESH);
+      const int tl = t / E, te = t - tl * E, link = 2 + tl;
       return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
     };
 
@@ -629,10 +654,10 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
 
   // ---- P4: one lane per env re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
   const int pe = (wv - (WAVES - G)) * GROUP + lane;  // env slot of this lane in P4 (waves WAVES-G .. WAVES-1)
-  if (wv >= WAVES - G && s_env[pe] != -1) {
+  if (wv >= WAVES - G && pe < E && s_env[pe] != -1) {
     const int n = s_env[pe] >= 0 ? s_env[pe] : -2 - s_env[pe];
     double q[6];
-    for (int i = 0; i < 6; i++) q[i] = s_q[i][pe];
+    for (int i = 0; i < 6; i++) q[i] = LDS_STATE ? s_q[i][pe] : joint_of_step<MODE>(P, actions, n, i);
     X3 TE = identity_x3();
 #pragma unroll 1
     for (int k = 0; k < 6; k++) {
@@ -640,8 +665,16 @@ __global__ void __launch_bounds__(THREADS) env_kernel(const KParams P, const flo
       sincos(q[k], &sn, &cs);
       fk_joint(TE, k, sn, cs);
     }
-    double opos[3] = {s_obst[0][pe], s_obst[1][pe], s_obst[2][pe]};
-    Q4 oq{s_obst[3][pe], s_obst[4][pe], s_obst[5][pe], s_obst[6][pe]};
+    double opos[3] = {0, 0, 0};
+    Q4 oq{0, 0, 0, 1};
+    if (HAS_OBST) {
+      if (LDS_STATE) {
+        opos[0] = s_obst[0][pe]; opos[1] = s_obst[1][pe]; opos[2] = s_obst[2][pe];
+        oq = Q4{s_obst[3][pe], s_obst[4][pe], s_obst[5][pe], s_obst[6][pe]};
+      } else {
+        obstacle_of_step<KIND>(P, n, opos, oq);
+      }
+    }
     const int step_count = B.step_count[n];
     Q4 eq = rot_to_quat(TE.r);
     double er, ep, ey;
@@ -886,7 +919,7 @@ struct Handle {
   SeedRec* d_seeds = nullptr;
   uint64_t seed = 0;
   int pp = 0;
-  int step_groups = 1;  // 64-env groups per workgroup of the step kernel (see urgym_create)
+  int step_envs = GROUP;  // envs per workgroup of the step kernel (see urgym_create)
   int reset_envs = 8;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
   char err[512] = {0};
   // timing
@@ -973,17 +1006,13 @@ KParams make_params(Handle* h, int copy_final) {
   P.pp = h->pp;
   P.copy_final = copy_final;
   P.envs = GROUP;
-  P.envs_log2 = 6;
   return P;
 }
 
 template <int MODE>
 void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s) {
-  int lg = 3;
-  while ((1 << lg) < envs && (1 << lg) < MAX_ENVS) lg++;   // power of two in [8, MAX_ENVS]: the kernel's LDS is sized for MAX_ENVS
-  envs = 1 << lg;
+  envs = envs < 1 ? 1 : (envs > MAX_ENVS ? MAX_ENVS : envs);   // the kernel's LDS is sized for MAX_ENVS
   P.envs = envs;
-  P.envs_log2 = lg;
   dim3 grid((h->cfg.num_envs + envs - 1) / envs), block(THREADS);
   switch (h->cfg.env_kind) {
     case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
@@ -1022,7 +1051,7 @@ int check_bound(Handle* h) {
 int do_step(Handle* h, const float* actions, hipStream_t s) {
   KParams P = make_params(h, 1);
   int slot = time_begin(h, 0, s);
-  launch_mode<MODE_STEP>(h, P, actions, GROUP * h->step_groups, s);
+  launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
   time_end(h, slot, s);
   if (h->cfg.auto_reset) {
     slot = time_begin(h, 1, s);
@@ -1040,9 +1069,9 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
   hipLaunchKernelGGL(build_list_kernel, dim3((N + 255) / 256), dim3(256), 0, s, mask, N, h->buf.done_list, h->buf.done_count + h->pp);
   KParams P = make_params(h, 0);
   if (mode == MODE_RESET)
-    launch_mode<MODE_RESET>(h, P, nullptr, GROUP * h->step_groups, s);
+    launch_mode<MODE_RESET>(h, P, nullptr, GROUP, s);
   else
-    launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP * h->step_groups, s);
+    launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP, s);
   // leave the consumed counter zeroed so the next step can append to either slot
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count, 0, 2 * sizeof(int32_t), s));
   HIP_TRY(h, hipGetLastError());
@@ -1106,22 +1135,46 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
   }
-  // Envs per step workgroup: 64 while that fills the chip in one round of resident workgroups (2 per CU), otherwise 128,
-  // where a finished lane draws a second obstacle query instead of idling behind the slowest query of its wave
-  // (DESIGN.md "work pool").  URGYM_STEP_GROUPS=1|2 overrides the choice (tuning / tests).
+  // Envs per step workgroup (E).  Measured on MI355X (DESIGN.md "launch geometry"): the kernel is bound by the latency of
+  // the GJK iteration chain, a round of resident workgroups takes ~(300 + 2.8 E) us almost independently of how full the
+  // chip is, and E = 64 (one hull per wave) is the most efficient shape.  So:
+  //   * N fits one round: the smallest power of two E >= 8 whose ceil(N / E) workgroups are all resident at once;
+  //   * N needs two rounds of 64: E = ceil(N / (2 * slots)) so that the second round is a full one (65536 -> 43);
+  //   * more rounds: E = 64.
+  // URGYM_STEP_ENVS / URGYM_RESET_ENVS override the choices (tuning / tests).
   {
-    int cus = 256;
+    int cus = 256, per_cu = 3;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    const int blocks64 = (cfg->num_envs + GROUP - 1) / GROUP;
-    h->step_groups = (MAX_GROUPS >= 2 && blocks64 > 2 * cus) ? 2 : 1;
+    hipError_t oe = hipSuccess;
+    switch (cfg->env_kind) {
+      case URGYM_ENV_ORI: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_ORI, MODE_STEP>, THREADS, 0); break;
+      case URGYM_ENV_OBS: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_OBS, MODE_STEP>, THREADS, 0); break;
+      case URGYM_ENV_STA: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_STA, MODE_STEP>, THREADS, 0); break;
+      default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP>, THREADS, 0); break;
+    }
+    if (oe != hipSuccess || per_cu < 1) per_cu = 3;
+    const long slots = (long)cus * per_cu;
+    const long n = cfg->num_envs;
+    long envs = GROUP;
+    if (n <= slots * GROUP) {
+      envs = 8;
+      while (envs < GROUP && (n + envs - 1) / envs > slots) envs *= 2;
+    } else {
+      const long rounds = (n + slots * GROUP - 1) / (slots * GROUP);
+      if (rounds <= 2) envs = (n + slots * rounds - 1) / (slots * rounds);
+    }
+    h->step_envs = (int)envs;
+    if (const char* ov = getenv("URGYM_STEP_ENVS")) {
+      const int v = atoi(ov);
+      if (v >= 1 && v <= MAX_ENVS) h->step_envs = v;
+    }
     if (const char* ov = getenv("URGYM_RESET_ENVS")) {
       const int r = atoi(ov);
-      if (r >= 8 && r <= MAX_ENVS) h->reset_envs = r;
+      if (r >= 1 && r <= MAX_ENVS) h->reset_envs = r;
     }
-    if (const char* ov = getenv("URGYM_STEP_GROUPS")) {
-      const int g = atoi(ov);
-      if (g >= 1 && g <= MAX_GROUPS) h->step_groups = g;
-    }
+    if (getenv("URGYM_VERBOSE"))
+      fprintf(stderr, "[urgym] device %d: %d CUs x %d resident step workgroups; N = %ld -> %d envs per step workgroup (%ld workgroups), %d per reset workgroup\n",
+              device, cus, per_cu, n, h->step_envs, (n + h->step_envs - 1) / h->step_envs, h->reset_envs);
   }
   *handle = h;
   return URGYM_OK;
