@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gjk-start", choices=("bullet", "guided"), default="bullet",
                     help="bullet = the reference's search start (parity-grade, default); guided = opt-in, NOT parity-grade")
+    ap.add_argument("--no-collision", action="store_true",
+                    help="check_collision=0: BASELINE.json configs[1] 'FK + pose-distance reward kernel only' (not the reference's step)")
     ap.add_argument("--rollout", action="store_true", help="enqueue all K steps through urgym_rollout (no Python per step)")
     args = ap.parse_args()
 
@@ -106,7 +108,8 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     n = args.num_envs
-    env = make_vec(args.env, num_envs=n, device=dev, seed=args.seed + 1000 * rank, gjk_start=int(args.gjk_start == "guided"))
+    env = make_vec(args.env, num_envs=n, device=dev, seed=args.seed + 1000 * rank, gjk_start=int(args.gjk_start == "guided"),
+                   check_collision=not args.no_collision)
     env.reset(seed=args.seed + 1000 * rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + rank)
@@ -123,14 +126,17 @@ def main():
 
     for k in range(args.warmup):
         one_step(k)
+    rollout_actions = None
+    if args.rollout and gathered is None:  # resident before the timed region, like the per-step action batches
+        rollout_actions = torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)])
     torch.cuda.synchronize(dev)
     env.enable_timing(True)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    if args.rollout and gathered is None:
-        env.rollout(torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)]))
+    if rollout_actions is not None:
+        env.rollout(rollout_actions)
     else:
         for k in range(args.steps):
             one_step(args.warmup + k)
@@ -167,7 +173,8 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.env} N={n} per GPU, random actions U(-1,1), auto-reset, seed {args.seed}",
+            "config": {"workload": f"{args.env} N={n} per GPU, random actions U(-1,1), auto-reset, seed {args.seed}"
+                                   + (", collision checks OFF (FK + reward only)" if args.no_collision else ""),
                        "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout),
                        "gjk_start": args.gjk_start},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -6,6 +6,8 @@ OUT=$R/gpurun_out/bench_configs.jsonl
 run() { timeout -k 10 300 python $R/bench.py --no-cpu-baseline "$@" | grep '^{' >> $OUT; }
 run --env UR5OriReach-v1 --num-envs 4096 --steps 300 --warmup 20
 run --env UR5OriReach-v1 --num-envs 4096 --steps 300 --warmup 20 --rollout
+run --env UR5OriReach-v1 --num-envs 4096 --steps 300 --warmup 20 --rollout --no-collision
+run --env UR5OriReach-v1 --num-envs 65536 --steps 300 --warmup 20 --rollout --no-collision
 run --env UR5ObsReach-v1 --num-envs 16384 --steps 200 --warmup 20
 run --env UR5DynReach-v1 --num-envs 65536 --steps 200 --warmup 20
 run --env UR5DynReach-v1 --num-envs 65536 --steps 200 --warmup 20 --rollout

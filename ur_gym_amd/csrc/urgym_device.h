@@ -227,25 +227,25 @@ struct HullGraph {
 // ranked identically on both sides.
 __device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) { return (x * d.x + y * d.y) + z * d.z; }
 
-// branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together)
-__device__ __forceinline__ void keep_better(double x, double y, double z, int id, D3 d, double& best, int& nxt, D3& pt) {
+// branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together).  Only the
+// value and the id are tracked; the winner's coordinates are fetched once, when the climb has ended.
+__device__ __forceinline__ void keep_better(double x, double y, double z, int id, D3 d, double& best, int& nxt) {
   const double t = vdot3(x, y, z, d);
   const bool g = t > best;
   best = g ? t : best;
   nxt = g ? id : nxt;
-  pt.x = g ? x : pt.x; pt.y = g ? y : pt.y; pt.z = g ? z : pt.z;
 }
 // four candidates packed as two D2 triples + their ids: the six 16-byte coordinate loads are issued before the first use
 // (eight at once would need 48 VGPRs for the coordinates alone and costs a wave per SIMD)
 __device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, const D2* xp, const D2* yp, const D2* zp, D3 d,
-                                             double& best, int& nxt, D3& pt) {
+                                             double& best, int& nxt) {
   const D2 x0 = xp[0], x1 = xp[1];
   const D2 y0 = yp[0], y1 = yp[1];
   const D2 z0 = zp[0], z1 = zp[1];
-  keep_better(x0.a, y0.a, z0.a, i0, d, best, nxt, pt);
-  keep_better(x0.b, y0.b, z0.b, i1, d, best, nxt, pt);
-  keep_better(x1.a, y1.a, z1.a, i2, d, best, nxt, pt);
-  keep_better(x1.b, y1.b, z1.b, i3, d, best, nxt, pt);
+  keep_better(x0.a, y0.a, z0.a, i0, d, best, nxt);
+  keep_better(x0.b, y0.b, z0.b, i1, d, best, nxt);
+  keep_better(x1.a, y1.a, z1.a, i2, d, best, nxt);
+  keep_better(x1.b, y1.b, z1.b, i3, d, best, nxt);
 }
 
 // Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
@@ -255,22 +255,23 @@ __device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, co
 // One climbing step = one round trip: the whole 224-byte record of the current vertex is fetched at once.
 __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d, int& cur) {
   double best;
-  D3 pt;
+  D3 pt = d3(0, 0, 0);
+  bool have_pt = false;
   if (cur < 0) {
     const SeedRec& S = g.seeds[h];
     best = -1.0e300;
-    pt = d3(0, 0, 0);
     int c = 0;
     const U8 ia = S.id[0], ib = S.id[1];
-    keep_best_of4(ia.v[0], ia.v[1], ia.v[2], ia.v[3], &S.x[0], &S.y[0], &S.z[0], d, best, c, pt);
-    keep_best_of4(ia.v[4], ia.v[5], ia.v[6], ia.v[7], &S.x[2], &S.y[2], &S.z[2], d, best, c, pt);
-    keep_best_of4(ib.v[0], ib.v[1], ib.v[2], ib.v[3], &S.x[4], &S.y[4], &S.z[4], d, best, c, pt);
-    keep_best_of4(ib.v[4], ib.v[5], ib.v[6], ib.v[7], &S.x[6], &S.y[6], &S.z[6], d, best, c, pt);
+    keep_best_of4(ia.v[0], ia.v[1], ia.v[2], ia.v[3], &S.x[0], &S.y[0], &S.z[0], d, best, c);
+    keep_best_of4(ia.v[4], ia.v[5], ia.v[6], ia.v[7], &S.x[2], &S.y[2], &S.z[2], d, best, c);
+    keep_best_of4(ib.v[0], ib.v[1], ib.v[2], ib.v[3], &S.x[4], &S.y[4], &S.z[4], d, best, c);
+    keep_best_of4(ib.v[4], ib.v[5], ib.v[6], ib.v[7], &S.x[6], &S.y[6], &S.z[6], d, best, c);
     cur = c;
   } else {
     const double* p = g.verts + 3 * cur;
     pt = d3(p[0], p[1], p[2]);
     best = vdot3(pt.x, pt.y, pt.z, d);
+    have_pt = true;
   }
   for (;;) {
     int nxt = cur;
@@ -279,12 +280,17 @@ __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d
       const NbrRec& R = g.recs[rec];
       const int nextrec = R.next;
       const U8 id = R.id;  // header + ids travel with the first half's coordinates
-      keep_best_of4(id.v[0], id.v[1], id.v[2], id.v[3], &R.x[0], &R.y[0], &R.z[0], d, best, nxt, pt);
-      keep_best_of4(id.v[4], id.v[5], id.v[6], id.v[7], &R.x[2], &R.y[2], &R.z[2], d, best, nxt, pt);
+      keep_best_of4(id.v[0], id.v[1], id.v[2], id.v[3], &R.x[0], &R.y[0], &R.z[0], d, best, nxt);
+      keep_best_of4(id.v[4], id.v[5], id.v[6], id.v[7], &R.x[2], &R.y[2], &R.z[2], d, best, nxt);
       rec = nextrec;
     } while (rec >= 0);
     if (nxt == cur) break;
     cur = nxt;
+    have_pt = false;
+  }
+  if (!have_pt) {  // the climb moved (or started from the seeds): one more load for the winner's coordinates
+    const double* p = g.verts + 3 * cur;
+    pt = d3(p[0], p[1], p[2]);
   }
   return pt;
 }
@@ -432,24 +438,28 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     }
     nv = s0 + e * t;
     uc = ud = false;
-  } else if (n == 3) {
-    int m;
-    nv = tri_closest(ldw(T, 0), ldw(T, 1), w, m);
-    ua = m & 1; ub = m & 2; uc = m & 4; ud = false;
   } else {
-    // faces in Bullet's order: ABC|D, ACD|B, ADB|C, BDC|A
+    // n == 3: the triangle itself.  n == 4: the faces in Bullet's order ABC|D, ACD|B, ADB|C, BDC|A, each only when the
+    // origin lies on its outer side.  One loop (and ONE instance of the triangle routine) serves both: a lane with a
+    // triangle simply takes part in the first trip only.
+    const bool tetra = (n == 4);
+    const int nf = tetra ? 4 : 1;
     double best = 1.0e300;
     bool any_out = false, degen = false;
     ua = ub = uc = ud = false;
 #pragma unroll 1
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < nf; f++) {
       const int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
       const int io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
       D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
-      D3 nrm = cross(b - a, c - a);
-      double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
-      if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
-      else if (signp * signd < 0.0) {
+      bool eval = true;
+      if (tetra) {
+        D3 nrm = cross(b - a, c - a);
+        double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
+        if (signd * signd < (1.0e-8 * 1.0e-8)) { degen = true; eval = false; }
+        else eval = (signp * signd < 0.0);
+      }
+      if (eval) {
         int m3;
         D3 pt = tri_closest(a, b, c, m3);
         double l = len2(pt);
