@@ -916,7 +916,7 @@ struct Handle {
   int obs_dim = 0, goal_dim = 0;
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
-  SeedRec* d_seeds = nullptr;
+  unsigned short* d_dirmap = nullptr;
   uint64_t seed = 0;
   int pp = 0;
   int step_envs = GROUP;  // envs per workgroup of the step kernel (see urgym_create)
@@ -998,7 +998,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.buf = h->buf;
   P.graph.verts = h->d_verts64;
   P.graph.recs = h->d_recs;
-  P.graph.seeds = h->d_seeds;
+  P.graph.dirmap = h->d_dirmap;
   P.obs_dim = h->obs_dim;
   P.goal_dim = h->goal_dim;
   P.seed_lo = (uint32_t)h->seed;
@@ -1127,11 +1127,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   };
   e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
-  if (e == hipSuccess) e = upload((void**)&h->d_seeds, tabs.seeds, sizeof(tabs.seeds));
+  if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
   if (e != hipSuccess) {
     if (h->d_verts64) hipFree(h->d_verts64);
     if (h->d_recs) hipFree(h->d_recs);
-    if (h->d_seeds) hipFree(h->d_seeds);
+    if (h->d_dirmap) hipFree(h->d_dirmap);
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
   }
@@ -1187,7 +1187,7 @@ int urgym_destroy(void* handle) {
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
-  if (h->d_seeds) hipFree(h->d_seeds);
+  if (h->d_dirmap) hipFree(h->d_dirmap);
   delete h;
   return URGYM_OK;
 }
@@ -1253,7 +1253,7 @@ int urgym_probe_closest(void* handle, int count, const int* type_a, const double
   HIP_TRY(h, hipSetDevice(h->device));
   if (count == 0) return URGYM_OK;
   HullGraph g;
-  g.verts = h->d_verts64; g.recs = h->d_recs; g.seeds = h->d_seeds;
+  g.verts = h->d_verts64; g.recs = h->d_recs; g.dirmap = h->d_dirmap;
   hipLaunchKernelGGL(probe_closest_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, g, count, type_a, par_a, pose_a,
                      type_b, par_b, pose_b, threshold, out_dist, out_info);
   HIP_TRY(h, hipGetLastError());

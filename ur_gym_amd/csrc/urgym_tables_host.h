@@ -10,11 +10,10 @@ namespace urgym {
 
 struct HostTables {
   std::vector<NbrRec> recs;
-  SeedRec seeds[6];
+  std::vector<unsigned short> dirmap;  // [6][DIRMAP_CELLS]
 };
 
 inline HostTables build_host_tables() {
-  static_assert(UR5E_NUM_SEEDS == HULL_SEEDS, "seed table width");
   HostTables t;
   const int NV = UR5E_NUM_HULL_VERTS;
   t.recs.resize(NV);
@@ -45,13 +44,26 @@ inline HostTables build_host_tables() {
       slot++;
     }
   }
+  // direction map: support vertex (exact float64 scan, first maximum like Bullet's) of every cell-centre direction
+  const int G = DIRMAP_G;
+  t.dirmap.resize((size_t)6 * DIRMAP_CELLS);
   for (int h = 0; h < 6; h++)
-    for (int s = 0; s < HULL_SEEDS; s++) {
-      const int v = UR5E_SEEDS[h][s];
-      SeedRec& S = t.seeds[h];
-      S.id[s / 8].v[s % 8] = (unsigned short)v;
-      (&S.x[0].a)[s] = UR5E_HULL_VERTS[v][0]; (&S.y[0].a)[s] = UR5E_HULL_VERTS[v][1]; (&S.z[0].a)[s] = UR5E_HULL_VERTS[v][2];
-    }
+    for (int face = 0; face < 6; face++)
+      for (int iv = 0; iv < G; iv++)
+        for (int iu = 0; iu < G; iu++) {
+          const int axis = face / 2;
+          double d[3];
+          d[axis] = (face & 1) ? -1.0 : 1.0;
+          d[(axis + 1) % 3] = (iu + 0.5) / G * 2.0 - 1.0;
+          d[(axis + 2) % 3] = (iv + 0.5) / G * 2.0 - 1.0;
+          int best = UR5E_HULL_OFFSET[h];
+          double bv = -1.0e300;
+          for (int k = UR5E_HULL_OFFSET[h]; k < UR5E_HULL_OFFSET[h + 1]; k++) {
+            const double val = (UR5E_HULL_VERTS[k][0] * d[0] + UR5E_HULL_VERTS[k][1] * d[1]) + UR5E_HULL_VERTS[k][2] * d[2];
+            if (val > bv) { bv = val; best = k; }
+          }
+          t.dirmap[(size_t)h * DIRMAP_CELLS + (face * G + iv) * G + iu] = (unsigned short)best;
+        }
   return t;
 }
 
