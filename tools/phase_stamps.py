@@ -12,10 +12,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--env", default="UR5DynReach-v1")
 ap.add_argument("--num-envs", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=12)
+ap.add_argument("--reset-kernel", action="store_true", help="library built with -DURGYM_STAMP_MODE=1: stamps of the auto-reset kernel")
+ap.add_argument("--lib", default="liburgym_stamps.so")
 ap.add_argument("--envs-per-block", type=int, default=64, help="forces URGYM_STEP_ENVS so that the stamp layout is known")
 args = ap.parse_args()
 os.environ["URGYM_STEP_ENVS"] = str(args.envs_per_block)
-_native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", "liburgym_stamps.so")
+_native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", args.lib)
 from ur_gym_amd import make_vec
 
 env = make_vec(args.env, num_envs=args.num_envs, seed=5)
@@ -26,12 +28,19 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 groups = args.envs_per_block
 blocks = min(8192, (args.num_envs + groups - 1) // groups)
+if args.reset_kernel:
+    groups = int(os.environ.get('URGYM_RESET_ENVS', '4'))
+    blocks = 2048  # upper bound; only the workgroups of the LAST launch are kept below
 W, S = int(os.environ.get("URGYM_WAVES", "4")), 12
 buf = np.zeros(blocks * W * S, dtype=np.uint64)
 lib = env.lib
 lib.urgym_debug_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.urgym_debug_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
 st = buf.reshape(blocks, W, S).astype(np.int64)
+if args.reset_kernel:
+    t_last = st[:, 0, 8].max()
+    st = st[(st[:, 0, 8] > t_last - 100000) & (st[:, 0, 9] >= st[:, 0, 8])]  # started within the last millisecond
+    blocks = len(st)
 t0 = st[:, :, 0].min(axis=1, keepdims=True)
 # s_memtime counts shader cycles, s_memrealtime 100 MHz: calibrate one against the other over the block lifetimes
 real = (st[:, :, 9] - st[:, :, 8]).astype(np.float64)

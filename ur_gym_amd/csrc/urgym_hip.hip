@@ -366,11 +366,14 @@ __device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double
 // Diagnostic build only (-DURGYM_STAMPS): per-wave s_memtime stamps of the step kernel's phases (tools/phase_stamps.py).
 // The stamps go to a buffer of their own; no output value depends on them.  Not compiled into the product.
 #ifdef URGYM_STAMPS
+#ifndef URGYM_STAMP_MODE
+#define URGYM_STAMP_MODE 0  /* MODE_STEP; 1 = the auto-reset kernel */
+#endif
 constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 12;
 __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP(k, v)                                                                                         \
   do {                                                                                                      \
-    if (MODE == MODE_STEP && lane == 0 && blockIdx.x < STAMP_BLOCKS)                                        \
+    if (MODE == URGYM_STAMP_MODE && lane == 0 && blockIdx.x < STAMP_BLOCKS)                                        \
       g_stamps[((size_t)blockIdx.x * WAVES + wv) * STAMP_SLOTS + (k)] = (unsigned long long)(v);            \
   } while (0)
 #define STAMP_TIME(k) STAMP(k, __builtin_amdgcn_s_memtime())
@@ -920,7 +923,7 @@ struct Handle {
   uint64_t seed = 0;
   int pp = 0;
   int step_envs = GROUP;  // envs per workgroup of the step kernel (see urgym_create)
-  int reset_envs = 8;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
+  int reset_envs = 4;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
   char err[512] = {0};
   // timing
   bool timing = false;
