@@ -1167,6 +1167,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (rounds <= 2) envs = (n + slots * rounds - 1) / (slots * rounds);
     }
     h->step_envs = (int)envs;
+    // auto-reset kernel: ~1 % of the envs finish per step; keep that to about one workgroup per CU (4 envs at N = 65536,
+    // 8 at 262144): it is pure latency, smaller workgroups shorten the wave-wide maxima, more than one per CU queue up
+    int renvs = 4;
+    while (renvs < GROUP && n / 100 > (long)renvs * (cus + cus / 4)) renvs *= 2;
+    h->reset_envs = renvs;
     if (const char* ov = getenv("URGYM_STEP_ENVS")) {
       const int v = atoi(ov);
       if (v >= 1 && v <= MAX_ENVS) h->step_envs = v;
