@@ -51,7 +51,7 @@ def cpu_baseline(env_id, seed, budget_s=12.0):
 
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     kind = _abi.ENV_IDS[env_id]
-    n = 2048
+    n = max(2048, 64 * cores)  # enough envs per host thread that the thread pool is not the thing measured
     env = ob.OracleEnv(kind, n, threads=cores)
     env.reset(seed=seed)
     rng = np.random.default_rng(seed)
@@ -61,7 +61,7 @@ def cpu_baseline(env_id, seed, budget_s=12.0):
     for k in range(2):
         env.step(acts[k])
     per_step = (time.perf_counter() - t0) / 2
-    steps = int(max(4, min(200, budget_s / max(per_step, 1e-6))))
+    steps = int(max(4, min(400, budget_s / max(per_step, 1e-6))))
     t0 = time.perf_counter()
     for k in range(steps):
         env.step(acts[k % len(acts)])

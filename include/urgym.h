@@ -48,7 +48,7 @@ enum {
  * BULLET: the world +Y axis, as btGjkPairDetector is entered by btConvexConvexAlgorithm -- the search then visits the
  *         same simplices as the reference's Bullet build (default; what every parity test pins).
  * GUIDED: the line from the other shape's centre to the mid point of the link's bounding capsule -- about half the
- *         iterations, ~1.6x the step rate.  NOT parity-grade: Bullet's answer is not path-independent (its
+ *         iterations (a few % of step rate since the hull search starts from a direction map).  NOT parity-grade: Bullet's answer is not path-independent (its
  *         degenerate-simplex / no-progress exits return the current iterate), so on these finely faceted hulls the two
  *         modes differ by > 1e-6 m on ~1.5 % and > 1e-5 m on ~0.15 % of the queries, worst seen ~1e-4 m.  Opt-in for
  *         training runs that do not need the reference's exact numbers; see DESIGN.md "GJK start". */
