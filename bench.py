@@ -100,8 +100,14 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # URGYM_BENCH_REHEARSE=1: rehearsal of the N>1 control flow on a ONE-GPU box (gloo, every rank on cuda:0); never a result
+        rehearse = os.environ.get("URGYM_BENCH_REHEARSE") == "1"
+        if rehearse:
+            local_rank = 0
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from ur_gym_amd import make_vec
 
@@ -148,7 +154,7 @@ def main():
     step_us, reset_us, launches = env.query_timing()
     env.enable_timing(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

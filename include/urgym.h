@@ -136,7 +136,10 @@ int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg);
 /* Observation layout: obs_dim = 18|26|35|29, goal_dim = 6|3|6|6 (core.py:241-247; reach.py:189,307,653,453-457). */
 int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
 
-/* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device`. */
+/* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device` (hull neighbour
+ * records, direction maps) and fixes the launch geometry for cfg->num_envs.  Environment variables read here, all optional
+ * and none of them changes a result: URGYM_STEP_ENVS / URGYM_RESET_ENVS (envs per workgroup of the step / auto-reset
+ * kernel, 1..64; tuning and tests), URGYM_VERBOSE (print the chosen geometry to stderr). */
 int urgym_create(const urgym_config* cfg, int device, void** handle);
 int urgym_destroy(void* handle);
 

@@ -452,3 +452,25 @@ def test_full_size_properties():
     env.close()
     env2.close()
     env3.close()
+
+
+@pytest.mark.parametrize("step_envs,reset_envs", [(5, 1), (37, 3), (64, 64)])
+def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs, reset_envs):
+    """The envs-per-workgroup choices of urgym_create (URGYM_STEP_ENVS / URGYM_RESET_ENVS override them) are pure
+    scheduling: any value must give the oracle's results — odd sizes, one env per reset workgroup, full 64."""
+    monkeypatch.setenv("URGYM_STEP_ENVS", str(step_envs))
+    monkeypatch.setenv("URGYM_RESET_ENVS", str(reset_envs))
+    kind, n, steps = _abi.ENV_DYN, 333, 30
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=41)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    env.reset(seed=41)
+    orc.reset(seed=41)
+    rng = np.random.default_rng(41)
+    finished = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        d, _ = step_both(oracle, kind, env, orc, a, where=f"geometry {step_envs}/{reset_envs} step {t}")
+        finished += d
+    assert finished > 5
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
