@@ -474,3 +474,58 @@ def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs,
     assert finished > 5
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
     env.close()
+
+
+def test_c_abi_error_behaviour_and_streams():
+    """Error paths of the C-ABI on a GPU box (bad config, unbound handle, null actions) and stream semantics: two
+    handles driven on two non-default streams give the same results as on the default stream."""
+    import ctypes as C
+
+    from ur_gym_amd import _native
+
+    lib = _native.lib()
+    cfg = _abi.Config()
+    assert lib.urgym_config_default(_abi.ENV_DYN, 128, C.byref(cfg)) == 0
+    h = C.c_void_p()
+    bad = _abi.Config.from_buffer_copy(cfg)
+    bad.gjk_start = 7
+    assert lib.urgym_create(C.byref(bad), 0, C.byref(h)) != 0            # unknown search start
+    bad = _abi.Config.from_buffer_copy(cfg)
+    bad.num_envs = 0
+    assert lib.urgym_create(C.byref(bad), 0, C.byref(h)) != 0            # no envs
+    assert lib.urgym_create(C.byref(cfg), 10 ** 6, C.byref(h)) != 0       # no such device
+    assert lib.urgym_create(C.byref(cfg), 0, C.byref(h)) == 0
+    assert lib.urgym_step(h, None, None) != 0                             # not bound yet
+    lib.urgym_last_error.restype = C.c_char_p
+    assert b"bind" in lib.urgym_last_error(h)
+    assert lib.urgym_destroy(h) == 0
+
+    # same seeds, same actions, three ways of scheduling: default stream, and two envs interleaved on side streams
+    n, steps = 300, 12
+    acts = torch.rand((steps, n, 6), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9)) * 2 - 1
+    ref = make_vec("UR5DynReach-v1", num_envs=n, seed=77)
+    ref.reset(seed=77)
+    for k in range(steps):
+        ref.step(acts[k])
+    torch.cuda.synchronize()
+    want = {k: ref.buf[k].clone() for k in ("observation", "reward", "terminated", "truncated")}
+    want_state = ref.get_state()
+    ref.close()
+    envs = [make_vec("UR5DynReach-v1", num_envs=n, seed=77) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for e, st in zip(envs, streams):
+        with torch.cuda.stream(st):
+            e.reset(seed=77)
+    for k in range(steps):
+        for e, st in zip(envs, streams):
+            with torch.cuda.stream(st):
+                e.step(acts[k])
+    torch.cuda.synchronize()
+    for e in envs:
+        for k, v in want.items():
+            assert torch.equal(e.buf[k], v), k
+        st = e.get_state()
+        for k in ("q", "link_dist", "step_count", "episode_id"):
+            assert np.array_equal(st[k], want_state[k]), k
+        e.close()
