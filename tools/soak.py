@@ -1,0 +1,31 @@
+"""Soak run on the GPU box: many steps of every env kind at the bench size, checking the per-env status word, finiteness
+of every output and basic invariants (step counts within the TimeLimit, flags consistent).  Diagnostic, not a benchmark."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ur_gym_amd import make_vec
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+for env_id, n in (("UR5OriReach-v1", 65536), ("UR5ObsReach-v1", 65536), ("UR5StaReach-v1", 65536), ("UR5DynReach-v1", 65536)):
+    env = make_vec(env_id, num_envs=n, seed=123)
+    env.reset(seed=123)
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.rand((50, n, 6), device="cuda", generator=gen) * 2 - 1
+    t0 = time.time()
+    term = trunc = succ = coll = 0
+    for k in range(steps):
+        obs, rew, te, tr, info = env.step(acts[k % 50])
+        if k % 100 == 99:
+            assert torch.isfinite(obs["observation"]).all() and torch.isfinite(rew).all(), (env_id, k)
+            # 8 = URGYM_STATUS_PENETRATION: an obstacle went deeper than the collision margins into a link and the distance
+            # was clamped (no EPA depth, DESIGN.md "deviations"); expected in Obs / Sta, whose reward consumes it
+            assert int((env.buf["status"] & ~8 != 0).sum()) == 0, (env_id, k, torch.unique(env.buf["status"]))
+            assert int(env.buf["step_count"].max()) < 100 and int(env.buf["step_count"].min()) >= 0
+            assert not bool((env.buf["is_success"].bool() & env.buf["collision"].bool()).any())
+        term += int(te.sum()); trunc += int(tr.sum()); succ += int(info["is_success"].sum()); coll += int(env.buf["collision"].sum())
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    print(f"{env_id}: {steps} steps x {n} envs ok in {dt:.1f} s ({steps * n / dt / 1e6:.1f} M steps/s incl. host checks); "
+          f"terminated {term} (collisions {coll}, successes {succ}), truncated {trunc}, "
+          f"envs that ever clamped a penetration: {int((env.buf['status'] & 8 != 0).sum())}", flush=True)
+    env.close()
