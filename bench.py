@@ -67,8 +67,20 @@ def cpu_baseline(env_id, seed, budget_s=12.0):
         env.step(acts[k % len(acts)])
     dt = time.perf_counter() - t0
     env.close()
+    # the same restatement on ONE host thread, ~2 s
+    n1 = 256
+    env1 = ob.OracleEnv(kind, n1, threads=1)
+    env1.reset(seed=seed)
+    t1 = time.perf_counter()
+    s1 = 0
+    while time.perf_counter() - t1 < 2.0:
+        env1.step(acts[s1 % len(acts)][:n1])
+        s1 += 1
+    d1 = time.perf_counter() - t1
+    env1.close()
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {steps} steps of {env_id}, random actions, auto-reset on ({dt:.1f} s)"}
+            "sample": f"{n} envs x {steps} steps of {env_id}, random actions, auto-reset on ({dt:.1f} s)",
+            "single_thread_value": n1 * s1 / d1, "single_thread_sample": f"{n1} envs x {s1} steps ({d1:.1f} s)"}
 
 
 def main():
