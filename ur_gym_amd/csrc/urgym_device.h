@@ -233,7 +233,11 @@ __device__ __forceinline__ int dirmap_cell(D3 d) {  // float32 is plenty: any ce
   const float v = axis == 0 ? z : (axis == 1 ? x : y);
   float am = fabsf(m);
   if (!(am > 0.0f)) am = 1.0f;
+#ifdef URGYM_HOST_HARNESS
   const float inv = 1.0f / am;
+#else
+  const float inv = __builtin_amdgcn_rcpf(am);  // 1 ulp is plenty: the cell only picks where the exact climb starts
+#endif
   int iu = (int)((u * inv + 1.0f) * (0.5f * DIRMAP_G));
   int iv = (int)((v * inv + 1.0f) * (0.5f * DIRMAP_G));
   iu = iu < 0 ? 0 : (iu > DIRMAP_G - 1 ? DIRMAP_G - 1 : iu);
@@ -442,37 +446,52 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     uc = ud = false;
   } else {
     // n == 3: the triangle itself.  n == 4: the faces in Bullet's order ABC|D, ACD|B, ADB|C, BDC|A, each only when the
-    // origin lies on its outer side.  One loop (and ONE instance of the triangle routine) serves both: a lane with a
-    // triangle simply takes part in the first trip only.
+    // origin lies on its outer side.  Two passes: (1) the four plane tests, which every lane with a tetrahedron needs,
+    // leave a bit mask of the faces to evaluate; (2) each lane then works through ITS faces, lowest first (Bullet's order:
+    // ties go to the earlier face).  The lanes of a wave rarely have more than two such faces, so pass 2 runs the (one)
+    // triangle routine about twice per wave-wide iteration instead of four times; a lane with a triangle has one "face".
     const bool tetra = (n == 4);
-    const int nf = tetra ? 4 : 1;
+    auto face_vertices = [](int f, int& ia, int& ib, int& ic, int& io) {
+      ia = (f == 3) ? 1 : 0;
+      ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3);
+      ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
+      io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
+    };
+    int todo = 1;  // triangle: just face 0 = (w0, w1, w2)
+    bool degen = false;
+    if (tetra) {
+      todo = 0;
+#pragma unroll 1
+      for (int f = 0; f < 4; f++) {
+        int ia, ib, ic, io;
+        face_vertices(f, ia, ib, ic, io);
+        const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
+        const D3 nrm = cross(b - a, c - a);
+        const double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
+        if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
+        else if (signp * signd < 0.0) todo |= 1 << f;
+      }
+    }
     double best = 1.0e300;
-    bool any_out = false, degen = false;
+    bool any_out = false;
     ua = ub = uc = ud = false;
 #pragma unroll 1
-    for (int f = 0; f < nf; f++) {
-      const int ia = (f == 3) ? 1 : 0, ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3), ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
-      const int io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
-      D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
-      bool eval = true;
-      if (tetra) {
-        D3 nrm = cross(b - a, c - a);
-        double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
-        if (signd * signd < (1.0e-8 * 1.0e-8)) { degen = true; eval = false; }
-        else eval = (signp * signd < 0.0);
+    while (todo) {
+      const int f = __builtin_ctz((unsigned)todo);
+      todo &= todo - 1;
+      int ia, ib, ic, io;
+      face_vertices(f, ia, ib, ic, io);
+      const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
+      int m3;
+      const D3 pt = tri_closest(a, b, c, m3);
+      const double l = len2(pt);
+      if (!any_out || l < best) {
+        best = l;
+        nv = pt;
+        const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+        ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
       }
-      if (eval) {
-        int m3;
-        D3 pt = tri_closest(a, b, c, m3);
-        double l = len2(pt);
-        if (!any_out || l < best) {
-          best = l;
-          nv = pt;
-          const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
-          ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
-        }
-        any_out = true;
-      }
+      any_out = true;
     }
     if (degen) {
       valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
