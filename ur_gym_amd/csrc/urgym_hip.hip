@@ -207,40 +207,36 @@ __device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const d
   }
 }
 
-// ---- RESET: one lane samples a new episode (reach.py:197-200, 313-326, 664-683; samplers utils.py:81-100)
-template <int KIND>
-__device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
+// ---- RESET: sampling of a new episode (reach.py:197-200, 313-326, 664-683; samplers utils.py:81-100).
+// Every test of a draw is a pure function of (seed, env, episode, attempt), so the accepted draw — the FIRST attempt that
+// passes — can be searched in any order.
+
+// Dyn only: does draw `attempt` pass the start->end travel test (reach.py:675)?  Needs just the two positions (Philox
+// blocks 1..3); 83 % of the draws fail here.
+__device__ __forceinline__ bool dyn_travel_ok(const KParams& P, int n, uint32_t episode, int attempt) {
   const urgym_config& cfg = P.cfg;
-  const urgym_buffers& B = P.buf;
-  const int N = cfg.num_envs;
-  const double DEG = 3.141592653589793 / 180.0;
-  uint32_t episode = (uint32_t)B.episode_id[n];
-  double goal[6] = {0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
-  for (int attempt = 0;; attempt++) {
-    if (KIND == URGYM_ENV_DYN) {
-      // Dyn rejects ~83 % of its draws on the start->end travel alone (reach.py:675).  Skip ahead to the next draw that
-      // passes that test before doing anything expensive: only the two positions are needed (Philox blocks 1..3), and
-      // the lanes of a wave then meet at the target-clearance query below a handful of times instead of ~30.  The
-      // accepted draw is the same one the sequential loop accepts: every test is a pure function of (env, episode, attempt).
-#pragma unroll 1
-      for (; attempt + 1 < cfg.max_reset_tries; attempt++) {
-        uint32_t o1[4], o2[4], o3[4];
-        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 1u, o1);
-        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 2u, o2);
-        philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 3u, o3);
-        const double us[3] = {u01(o1[1]), u01(o1[2]), u01(o1[3])};   // u[5], u[6], u[7]
-        const double ue[3] = {u01(o2[3]), u01(o3[0]), u01(o3[1])};   // u[11], u[12], u[13]
-        double d2 = 0.0, dd[3];
+  uint32_t o1[4], o2[4], o3[4];
+  philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 1u, o1);
+  philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 2u, o2);
+  philox4x32_10(P.seed_lo, P.seed_hi, (uint32_t)n, episode, (uint32_t)attempt, 3u, o3);
+  const double us[3] = {u01(o1[1]), u01(o1[2]), u01(o1[3])};   // u[5], u[6], u[7]
+  const double ue[3] = {u01(o2[3]), u01(o3[0]), u01(o3[1])};   // u[11], u[12], u[13]
+  double dd[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
-          const double a = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * us[i];
-          const double b = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * ue[i];
-          dd[i] = b - a;
-        }
-        d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
-        if (!(sqrt(d2) < cfg.min_travel)) break;
-      }
-    }
+  for (int i = 0; i < 3; i++) {
+    const double a = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * us[i];
+    const double b = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * ue[i];
+    dd[i] = b - a;
+  }
+  const double d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+  return !(sqrt(d2) < cfg.min_travel);
+}
+
+// One complete draw: goal, obstacle start (and end), every rejection test.  Returns true when the draw is REJECTED.
+template <int KIND>
+__device__ bool sample_attempt(const KParams& P, XRef slot, int n, uint32_t episode, int attempt, double goal[6], double st[6], double en[6]) {
+  const urgym_config& cfg = P.cfg;
+  const double DEG = 3.141592653589793 / 180.0;
     double u[20];
 #pragma unroll
     for (int blk = 0; blk < 5; blk++) {
@@ -255,7 +251,7 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
       goal[4] = 0.0 * DEG;
       goal[5] = (0.0 + (-180.0 - 0.0) * u[4]) * DEG;
     }
-    if (KIND == URGYM_ENV_ORI) break;
+    if (KIND == URGYM_ENV_ORI) return false;
 #pragma unroll
     for (int i = 0; i < 3; i++) st[i] = cfg.obst_low[i] + (cfg.obst_high[i] - cfg.obst_low[i]) * u[5 + i];
     {  // utils.sample_euler_obstacle
@@ -304,18 +300,71 @@ __device__ void sample_episode(const KParams& P, XRef slot, int n, int& flags) {
       double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
       fail = dist < cfg.target_clearance;
     }
-    if (!fail) break;
-    if (attempt + 1 >= cfg.max_reset_tries) {
-      flags |= URGYM_STATUS_RESET_EXHAUSTED;
-      break;
+    return fail;
+}
+
+// The search for the accepted draw, run by the WHOLE first wave of a RESET workgroup.  Env slot es = lane % E2 (E2 = E
+// rounded up to a power of two) is led by lane es; the 64 / E2 lanes {es + k E2} of a slot test the travel rule of the
+// draws base + k at once (Dyn), so the unluckiest env of a step — ~35 rejected draws among a few hundred resetting envs,
+// which used to set the latency of the whole reset kernel — is through in three rounds.  The leader then evaluates the
+// full draw (target <-> obstacle clearance through the GJK) and either accepts it or moves the base past it.  The result
+// is the draw the sequential loop of the reference accepts; max_reset_tries bounds it the same way.
+template <int KIND>
+__device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane, int n, int& flags) {
+  const urgym_config& cfg = P.cfg;
+  const urgym_buffers& B = P.buf;
+  const int N = cfg.num_envs;
+  int e2 = 1, sh = 0;
+  while (e2 < E) { e2 <<= 1; sh++; }
+  const int es = lane & (e2 - 1), k = lane >> sh, lpe = 64 >> sh;
+  const bool leader = (lane < E) && (n >= 0);
+  const int n_grp = __shfl(leader ? n : -1, es);
+  const uint32_t episode = n_grp >= 0 ? (uint32_t)B.episode_id[n_grp] : 0u;
+  unsigned long long stride = 0ull;  // bit es + k E2 of a ballot belongs to slot es: shift by es, keep every E2-th bit
+  for (int i = 0; i < 64; i += e2) stride |= 1ull << i;
+  double goal[6] = {0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
+  int attempt = 0;
+  bool done = !leader;
+#pragma unroll 1
+  for (;;) {
+    if (__ballot(!done) == 0ull) break;
+    if (KIND == URGYM_ENV_DYN) {
+      // every slot still searching advances to its next draw that passes the travel rule; the slots meet again at the
+      // (expensive) full evaluation below, so that it runs once per round for all of them
+      bool cand = done;  // finished / empty slots have nothing to look for
+#pragma unroll 1
+      for (;;) {
+        if (__ballot(!cand) == 0ull) break;
+        const int base = __shfl(attempt, es);
+        const bool searching = __shfl((int)!cand, es) != 0;
+        const int a = base + k;
+        bool pass = false;
+        if (searching) {
+          if (a + 1 < cfg.max_reset_tries) pass = dyn_travel_ok(P, n_grp, episode, a);
+          else pass = (a + 1 == cfg.max_reset_tries);  // the last permitted draw is evaluated whatever its travel
+        }
+        const unsigned long long m = (__ballot(pass) >> es) & stride;
+        if (!cand) {
+          if (m != 0ull) { attempt = base + (__builtin_ctzll(m) >> sh); cand = true; }
+          else attempt = base + lpe;
+        }
+      }
+    }
+    if (!done) {
+      const bool fail = sample_attempt<KIND>(P, slot, n, episode, attempt, goal, st, en);
+      if (!fail) done = true;
+      else if (attempt + 1 >= cfg.max_reset_tries) { flags |= URGYM_STATUS_RESET_EXHAUSTED; done = true; }
+      else attempt++;
     }
   }
-  for (int i = 0; i < 6; i++) SOA(B.goal, i, n, N) = goal[i];
-  if (KIND != URGYM_ENV_ORI) {
-    for (int i = 0; i < 6; i++) { SOA(B.obst_start, i, n, N) = st[i]; SOA(B.obst_end, i, n, N) = en[i]; }
+  if (leader) {
+    for (int i = 0; i < 6; i++) SOA(B.goal, i, n, N) = goal[i];
+    if (KIND != URGYM_ENV_ORI) {
+      for (int i = 0; i < 6; i++) { SOA(B.obst_start, i, n, N) = st[i]; SOA(B.obst_end, i, n, N) = en[i]; }
+    }
+    for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = cfg.neutral_q[i];
+    B.episode_id[n] = (int32_t)(episode + 1);
   }
-  for (int i = 0; i < 6; i++) SOA(B.q, i, n, N) = cfg.neutral_q[i];
-  B.episode_id[n] = (int32_t)(episode + 1);
 }
 
 // Joint k of env n for this launch: STEP = stored joint + float32(float32(clip(a) * pi32) * 0.1f) (UR5.py:273-279, 314);
@@ -430,14 +479,18 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
 
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
+  int n_slot = -1, flags_slot = 0;  // env of slot tid (lanes tid < E)
+  if (tid < E) {
+    const int idx = blockIdx.x * E + tid;
+    if (MODE == MODE_STEP) n_slot = idx < N ? idx : -1;
+    else n_slot = idx < list_count ? B.done_list[idx] : -1;
+  }
+  // RESET: the whole first wave searches the accepted draws of its (<= 64) env slots; writes goal / obstacle / q / episode_id
+  if (MODE == MODE_RESET && wv == 0) sample_episode_wave<KIND>(P, pose_slot, E, lane, n_slot, flags_slot);
   if (tid < E) {
     const int e = tid;
-    const int idx = blockIdx.x * E + e;
-    int n = -1;
-    if (MODE == MODE_STEP) n = idx < N ? idx : -1;
-    else n = idx < list_count ? B.done_list[idx] : -1;
-    int flags = 0;
-    if (MODE == MODE_RESET && n >= 0) sample_episode<KIND>(P, pose_slot, n, flags);  // writes goal / obstacle / q / episode_id
+    const int n = n_slot;
+    int flags = flags_slot;
     double q[6] = {0, 0, 0, 0, 0, 0};
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
