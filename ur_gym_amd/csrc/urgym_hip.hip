@@ -446,6 +446,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
   __shared__ int s_flags[MAX_ENVS];        // status bits | COLL_BIT
   __shared__ int s_env[MAX_ENVS];          // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
   __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
+  __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
   // ... and per-lane slots
   __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
 
@@ -469,7 +470,17 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
     list_count = B.done_count[P.pp];
     if ((int)blockIdx.x * E >= list_count) return;  // uniform for the whole workgroup
   }
-  if (tid == 0) { s_ticket = THREADS; s_pending = 0; }
+  if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
+  // STEP: the per-env phase P1 (joint check + culling) runs on the LAST wave while the others already start their obstacle
+  // queries — nothing a query needs comes from P1 (joints and obstacle are re-derived from global memory), only the pair
+  // masks do, and those are drawn late.  So the slots are initialised here, before the first barrier, and the barrier after
+  // P1 is dropped for STEP.  The last wave holds the fewest / shortest queries (ticket order), which hides its late start.
+  constexpr int P1_WAVE = (MODE == MODE_STEP) ? WAVES - 1 : 0;
+  if (MODE == MODE_STEP && tid < E) {
+    s_env[tid] = ((int)blockIdx.x * E + tid < N) ? (int)blockIdx.x * E + tid : -1;
+    s_flags[tid] = 0;
+    s_pairs[tid] = 0;
+  }
   STAMP_TIME(0);
   STAMP(8, __builtin_amdgcn_s_memrealtime());
 #ifdef URGYM_STAMPS
@@ -479,16 +490,17 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
 
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
-  int n_slot = -1, flags_slot = 0;  // env of slot tid (lanes tid < E)
-  if (tid < E) {
-    const int idx = blockIdx.x * E + tid;
+  const bool p1_lane = (wv == P1_WAVE) && (lane < E);  // E <= 64: one lane per env slot
+  int n_slot = -1, flags_slot = 0;  // env of slot `lane`
+  if (p1_lane) {
+    const int idx = blockIdx.x * E + lane;
     if (MODE == MODE_STEP) n_slot = idx < N ? idx : -1;
     else n_slot = idx < list_count ? B.done_list[idx] : -1;
   }
   // RESET: the whole first wave searches the accepted draws of its (<= 64) env slots; writes goal / obstacle / q / episode_id
   if (MODE == MODE_RESET && wv == 0) sample_episode_wave<KIND>(P, pose_slot, E, lane, n_slot, flags_slot);
-  if (tid < E) {
-    const int e = tid;
+  if (p1_lane) {
+    const int e = lane;
     const int n = n_slot;
     int flags = flags_slot;
     double q[6] = {0, 0, 0, 0, 0, 0};
@@ -506,7 +518,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
     }
     const bool live = (n >= 0 && finite);
     s_env[e] = live ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
-    s_flags[e] = flags;
+    if (MODE != MODE_STEP) s_flags[e] = flags;      // (STEP: zeroed before the first barrier; queries may already be OR-ing)
     if (LDS_STATE) {
       for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
       s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
@@ -547,7 +559,11 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
     if (pairs) atomicAdd(&s_pending, __popc(pairs));
   }
   STAMP_TIME(1);
-  __syncthreads();
+  if (MODE == MODE_STEP) {
+    if (wv == P1_WAVE && lane == 0) __hip_atomic_store(&s_p1done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  } else {
+    __syncthreads();
+  }
 
   // ---- P2 + P3: all closest-distance work of the workgroup goes through ONE inlined, resumable GJK body, fed from a
   //      work pool so that no lane waits for the slowest query of its wave:
@@ -581,6 +597,11 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       const int la = (item >> 13) & 7;
       const int n = s_env[e];
       if (n < 0) return false;
+      if (MODE == MODE_STEP) {  // P1 may not have judged this env yet: non-finite joints -> no query (same rule as P1)
+        bool finite = true;
+        for (int k = 0; k < 6; k++) finite = finite && (fabs(joint_of_step<MODE>(P, actions, n, k)) < 1.0e6);
+        if (!finite) return false;
+      }
       X3 T = identity_x3(), TA = identity_x3();
 #pragma unroll 1
       for (int k = 0; k < lb; k++) {
@@ -700,7 +721,10 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
           if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + (kind == 3 ? 5.0 : cfg.collision_margin));
         }
       }
-      if (__ballot(busy) == 0ull && !more_tickets && !more_pairs) break;  // nothing left for this wave to draw
+      // nothing left for this wave to draw (STEP: and the pair masks have been published)
+      if (__ballot(busy) == 0ull && !more_tickets && !more_pairs &&
+          (MODE != MODE_STEP || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0))
+        break;
     }
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
