@@ -139,7 +139,8 @@ int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
 /* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device` (hull neighbour
  * records, direction maps) and fixes the launch geometry for cfg->num_envs.  Environment variables read here, all optional
  * and none of them changes a result: URGYM_STEP_ENVS / URGYM_RESET_ENVS (envs per workgroup of the step / auto-reset
- * kernel, 1..64; tuning and tests), URGYM_VERBOSE (print the chosen geometry to stderr). */
+ * kernel, 1..64; tuning and tests), URGYM_PREFETCH (0: reset finished envs with a kernel after each step instead of inline
+ * from prefetched episode records), URGYM_VERBOSE (print the chosen geometry to stderr). */
 int urgym_create(const urgym_config* cfg, int device, void** handle);
 int urgym_destroy(void* handle);
 
@@ -173,6 +174,11 @@ int urgym_probe_closest(void* handle, int count, const int* type_a, const double
  * hipEvents on the launch stream; returns <0 if timing was not enabled. */
 int urgym_enable_timing(void* handle, int enable);
 int urgym_query_timing(void* handle, double* step_kernel_us, double* reset_kernel_us, int* launches);
+
+/* Average duration (us) of the overlapped refill launches covered by the most recent urgym_query_timing() call: the search
+ * for the next episodes of the envs that finished, which runs on a side stream under the following step (0 when the
+ * prefetched-record path is off).  Measurement hook only. */
+int urgym_query_refill_timing(void* handle, double* refill_us);
 
 const char* urgym_last_error(void* handle);
 

@@ -529,3 +529,59 @@ def test_c_abi_error_behaviour_and_streams():
         for k in ("q", "link_dist", "step_count", "episode_id"):
             assert np.array_equal(st[k], want_state[k]), k
         e.close()
+
+
+@pytest.mark.parametrize("prefetch", ["0", "1"])
+def test_auto_reset_paths_match_oracle(oracle, monkeypatch, prefetch):
+    """The two implementations of the auto-reset — a RESET kernel after each step (URGYM_PREFETCH=0) and the inline reset
+    from prefetched episode records refilled on a side stream (=1, default for the obstacle envs) — against the oracle, with
+    a mid-run edit of episode ids through set_state that makes every record stale (the fallback path must take over and
+    the records must recover)."""
+    monkeypatch.setenv("URGYM_PREFETCH", prefetch)
+    kind, n, steps = _abi.ENV_DYN, 400, 60
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=53)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    env.reset(seed=53)
+    orc.reset(seed=53)
+    rng = np.random.default_rng(53)
+    finished = 0
+    for t in range(steps):
+        if t == 20:  # stale records from here on: the episode counters jump
+            st = env.get_state()
+            bump = (np.arange(n) % 3).astype(st["episode_id"].dtype)
+            env.set_state({"episode_id": st["episode_id"] + bump})
+            orc.buf["episode_id"][...] = orc.buf["episode_id"] + bump
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        d, _ = step_both(oracle, kind, env, orc, a, where=f"prefetch={prefetch} step {t}")
+        finished += d
+    assert finished > 40
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+def test_prefetched_reset_is_bitwise_the_reset_kernel_at_scale(monkeypatch):
+    """65536 Dyn envs, 130 steps (past the step where every surviving env is truncated at once): the inline reset from
+    prefetched records must leave exactly the bits the RESET kernel leaves — outputs and state, every step."""
+    n, steps = 65536, 130
+    envs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("URGYM_PREFETCH", flag)
+        e = make_vec("UR5DynReach-v1", num_envs=n, seed=61)
+        e.reset(seed=61)
+        envs.append(e)
+    gen = torch.Generator(device="cuda").manual_seed(61)
+    for t in range(steps):
+        a = torch.rand((n, 6), device="cuda", generator=gen) * 2 - 1
+        for e in envs:
+            e.step(a)
+        torch.cuda.synchronize()
+        for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success", "collision",
+                  "final_observation", "status", "q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel",
+                  "link_dist", "step_count", "episode_id"):
+            x, y = envs[0].buf[k], envs[1].buf[k]
+            if k == "final_observation":
+                m = (envs[0].buf["terminated"] | envs[0].buf["truncated"]).bool()
+                x, y = x[m], y[m]
+            assert torch.equal(x, y) or torch.equal(torch.nan_to_num(x.double()), torch.nan_to_num(y.double())), (k, t)
+    for e in envs:
+        e.close()

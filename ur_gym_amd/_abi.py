@@ -99,6 +99,6 @@ EXPORTED_SYMBOLS = [
     "urgym_refresh",
     "urgym_probe_closest",
     "urgym_enable_timing",
-    "urgym_query_timing",
+    "urgym_query_timing", "urgym_query_refill_timing",
     "urgym_last_error",
 ]

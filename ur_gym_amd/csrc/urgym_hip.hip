@@ -36,6 +36,7 @@ constexpr int GROUP = 64;       // env slots per wave-wide pass
 #ifndef URGYM_MAX_ENVS
 #define URGYM_MAX_ENVS 64
 #endif
+constexpr int PREFETCH_MAX_ENVS = 32;       // envs per PREFETCH workgroup at most
 constexpr int MAX_ENVS = URGYM_MAX_ENVS;   // most envs one workgroup serves (KParams::envs); bounded by the 53 KB LDS budget of STEP
 #ifndef URGYM_WAVES
 #define URGYM_WAVES 4
@@ -53,7 +54,7 @@ __host__ __device__ constexpr int self_pair_bit(int la, int lb) {  // (1,3)(1,4)
   return PAIR_SELF + (la == 1 ? 0 : (la == 2 ? 4 : 7)) + (lb - (la + 2));
 }
 
-enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2 };
+enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_PREFETCH = 3 };
 enum { Q_TABLE = 0, Q_TRACK = 1, Q_SELF = 2 };
 
 // Bullet collision margins: hull 0.001; cylinder r=0.05 -> 0.005; table 0.04; track 0.006;
@@ -73,6 +74,13 @@ struct DevTables {
 };
 __constant__ DevTables c_tab;
 
+// Prefetched episode records (DESIGN.md "auto-reset off the critical path"): everything a reset produces is a pure function of
+// (seed, env, episode id), so the records of the next two episodes of every env are kept ready in handle-owned memory:
+// slot = episode & 1; fields per env (float64): goal 0..5, obstacle start 6..11, obstacle end 12..17, obstacle velocity 18..23,
+// obstacle quaternion 24..27, neutral-pose link distances 28..32; ints: the episode id the record is for (-1 = none), status.
+constexpr int REC_FIELDS = 33;
+enum { REC_GOAL = 0, REC_START = 6, REC_END = 12, REC_VEL = 18, REC_QUAT = 24, REC_LD = 28 };
+
 struct KParams {
   urgym_config cfg;
   urgym_buffers buf;
@@ -82,7 +90,22 @@ struct KParams {
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
   int envs;         // envs per workgroup, 1 .. MAX_ENVS (chosen per launch: see urgym_create / do_step)
+  // prefetched episode records (null / 0 when the feature is off)
+  double* rec_d;    // [2][REC_FIELDS][N]
+  int32_t* rec_i;   // [2][2][N]: {episode id of the record, status flags of its sampling}
+  int2* rlist;      // (env, episode) entries: STEP appends the slots it consumed (refilled under the next step), RESET the
+                    // episodes after the one it started (refilled synchronously), PREFETCH reads its work from here
+  int* rcount;      // number of entries in rlist
+  int rcap;         // capacity of rlist
+  int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
+  int prefetch;     // 1: STEP resets finished envs inline from valid records; RESET files refill entries
 };
+__device__ __forceinline__ double& REC(const KParams& P, int slot, int f, int n) {
+  return P.rec_d[((size_t)slot * REC_FIELDS + f) * P.cfg.num_envs + n];
+}
+__device__ __forceinline__ int32_t& RECI(const KParams& P, int slot, int j, int n) {
+  return P.rec_i[((size_t)slot * 2 + j) * P.cfg.num_envs + n];
+}
 
 __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
 
@@ -310,7 +333,7 @@ __device__ bool sample_attempt(const KParams& P, XRef slot, int n, uint32_t epis
 // full draw (target <-> obstacle clearance through the GJK) and either accepts it or moves the base past it.  The result
 // is the draw the sequential loop of the reference accepts; max_reset_tries bounds it the same way.
 template <int KIND>
-__device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane, int n, int& flags) {
+__device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane, int n, int key, bool to_record, int& flags, int& episode_used) {
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
   const int N = cfg.num_envs;
@@ -319,7 +342,10 @@ __device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane
   const int es = lane & (e2 - 1), k = lane >> sh, lpe = 64 >> sh;
   const bool leader = (lane < E) && (n >= 0);
   const int n_grp = __shfl(leader ? n : -1, es);
-  const uint32_t episode = n_grp >= 0 ? (uint32_t)B.episode_id[n_grp] : 0u;
+  // the episode id the draw is keyed with: the env's current one (live reset) or the entry's (prefetch)
+  const int key_leader = leader ? (to_record ? key : B.episode_id[n]) : 0;
+  const uint32_t episode = (uint32_t)__shfl(key_leader, es);
+  episode_used = (int)episode;
   unsigned long long stride = 0ull;  // bit es + k E2 of a ballot belongs to slot es: shift by es, keep every E2-th bit
   for (int i = 0; i < 64; i += e2) stride |= 1ull << i;
   double goal[6] = {0, 0, 0, 0, 0, 0}, st[6] = {0, 0, 0, 0, 0, 0}, en[6] = {0, 0, 0, 0, 0, 0};
@@ -357,7 +383,10 @@ __device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane
       else attempt++;
     }
   }
-  if (leader) {
+  if (leader && to_record) {
+    const int sl = (int)(episode & 1u);
+    for (int i = 0; i < 6; i++) { REC(P, sl, REC_GOAL + i, n) = goal[i]; REC(P, sl, REC_START + i, n) = st[i]; REC(P, sl, REC_END + i, n) = en[i]; }
+  } else if (leader) {
     for (int i = 0; i < 6; i++) SOA(B.goal, i, n, N) = goal[i];
     if (KIND != URGYM_ENV_ORI) {
       for (int i = 0; i < 6; i++) { SOA(B.obst_start, i, n, N) = st[i]; SOA(B.obst_end, i, n, N) = en[i]; }
@@ -372,7 +401,7 @@ __device__ void sample_episode_wave(const KParams& P, XRef slot, int E, int lane
 // launch does not modify before its last barrier, so any lane may re-derive it instead of keeping it in LDS.
 template <int MODE>
 __device__ __forceinline__ double joint_of_step(const KParams& P, const float* __restrict__ actions, int n, int k) {
-  if (MODE == MODE_RESET) return P.cfg.neutral_q[k];
+  if (MODE == MODE_RESET || MODE == MODE_PREFETCH) return P.cfg.neutral_q[k];
   double q = P.buf.q[(size_t)k * P.cfg.num_envs + n];
   if (MODE == MODE_STEP) {
     float a = actions[(size_t)n * 6 + k];
@@ -432,21 +461,26 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #endif
 
 template <int KIND, int MODE>
-__global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
+__global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
   // per-env slots (E = P.envs envs per workgroup, <= MAX_ENVS) ...
-  __shared__ double s_dist[5][MAX_ENVS];
+  // PREFETCH workgroups run UNDER a step kernel: with at most 32 envs and no joint array they need < 55 KB and share a CU with
+  // two step workgroups instead of displacing both
+  constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : MAX_ENVS;
+  constexpr bool LDS_Q = (MODE == MODE_REFRESH);  // RESET / PREFETCH: the joints are the neutral pose, a constant
+  __shared__ double s_dist[5][ME];
   // STEP launches re-derive the joints and the obstacle pose from global memory wherever they are needed (joint_of_step,
   // obstacle_of_step): 6.5 KB less LDS, which is what lets a third workgroup stay resident on the CU.  RESET / REFRESH
   // launches hand them from the sampling lane to the query lanes through LDS (global memory written by this launch is
   // not safely readable through the CU's L1).
   constexpr bool LDS_STATE = (MODE != MODE_STEP);
-  __shared__ double s_q[LDS_STATE ? 6 : 1][LDS_STATE ? MAX_ENVS : 1];      // joint vector
-  __shared__ double s_obst[LDS_STATE ? 7 : 1][LDS_STATE ? MAX_ENVS : 1];   // obstacle position + quaternion
-  __shared__ uint32_t s_pairs[MAX_ENVS];   // culling survivors: one bit per table / track / self pair (PAIR_* below)
-  __shared__ int s_flags[MAX_ENVS];        // status bits | COLL_BIT
-  __shared__ int s_env[MAX_ENVS];          // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
+  __shared__ double s_q[LDS_Q ? 6 : 1][LDS_Q ? ME : 1];                    // joint vector
+  __shared__ double s_obst[LDS_STATE ? 7 : 1][LDS_STATE ? ME : 1];         // obstacle position + quaternion
+  __shared__ uint32_t s_pairs[ME];         // culling survivors: one bit per table / track / self pair (PAIR_* below)
+  __shared__ int s_flags[ME];              // status bits | COLL_BIT
+  __shared__ int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
   __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
   __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
+  __shared__ int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
   __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
 
@@ -465,9 +499,10 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
   static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
 
+  if (blockIdx.x == 0 && tid == 0 && P.rzero) *P.rzero = 0;  // (before any early exit)
   int list_count = 0;
   if (MODE != MODE_STEP) {
-    list_count = B.done_count[P.pp];
+    list_count = (MODE == MODE_PREFETCH) ? min(*P.rcount, P.rcap) : B.done_count[P.pp];
     if ((int)blockIdx.x * E >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
@@ -492,13 +527,21 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
   const bool p1_lane = (wv == P1_WAVE) && (lane < E);  // E <= 64: one lane per env slot
   int n_slot = -1, flags_slot = 0;  // env of slot `lane`
+  int key_slot = 0;                 // PREFETCH: the episode id the record is for
   if (p1_lane) {
     const int idx = blockIdx.x * E + lane;
     if (MODE == MODE_STEP) n_slot = idx < N ? idx : -1;
-    else n_slot = idx < list_count ? B.done_list[idx] : -1;
+    else if (MODE == MODE_PREFETCH) {
+      if (idx < list_count) { const int2 ent = P.rlist[idx]; n_slot = ent.x; key_slot = ent.y; }
+    } else n_slot = idx < list_count ? B.done_list[idx] : -1;
   }
-  // RESET: the whole first wave searches the accepted draws of its (<= 64) env slots; writes goal / obstacle / q / episode_id
-  if (MODE == MODE_RESET && wv == 0) sample_episode_wave<KIND>(P, pose_slot, E, lane, n_slot, flags_slot);
+  // RESET / PREFETCH: the whole first wave searches the accepted draws of its (<= 64) env slots.  RESET writes goal /
+  // obstacle / q / episode_id of the live state, PREFETCH the goal / obstacle fields of the record slot.
+  if ((MODE == MODE_RESET || MODE == MODE_PREFETCH) && wv == 0) {
+    int episode_used = 0;
+    sample_episode_wave<KIND>(P, pose_slot, E, lane, n_slot, key_slot, MODE == MODE_PREFETCH, flags_slot, episode_used);
+    if (p1_lane) s_key[lane] = (MODE == MODE_PREFETCH) ? key_slot : episode_used + 1;
+  }
   if (p1_lane) {
     const int e = lane;
     const int n = n_slot;
@@ -511,16 +554,18 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       for (int i = 0; i < 6; i++) q[i] = joint_of_step<MODE>(P, actions, n, i);
       for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
       if (HAS_OBST && LDS_STATE) {
-        // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710)
-        for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_start, i, n, N);
-        oq = quat_from_rpy(SOA(B.obst_start, 3, n, N), SOA(B.obst_start, 4, n, N), SOA(B.obst_start, 5, n, N));
+        // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710); PREFETCH: the record's
+        double sp[6];
+        for (int i = 0; i < 6; i++) sp[i] = (MODE == MODE_PREFETCH) ? REC(P, key_slot & 1, REC_START + i, n) : SOA(B.obst_start, i, n, N);
+        for (int i = 0; i < 3; i++) opos[i] = sp[i];
+        oq = quat_from_rpy(sp[3], sp[4], sp[5]);
       }
     }
     const bool live = (n >= 0 && finite);
     s_env[e] = live ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
     if (MODE != MODE_STEP) s_flags[e] = flags;      // (STEP: zeroed before the first barrier; queries may already be OR-ing)
     if (LDS_STATE) {
-      for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
+      if (LDS_Q) for (int i = 0; i < 6; i++) s_q[i][e] = q[i];
       s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
       s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
     }
@@ -528,7 +573,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       for (int i = 0; i < 5; i++) s_dist[i][e] = (n >= 0) ? __builtin_nan("") : 1e30;
     // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
     uint32_t pairs = 0;
-    if (live && cfg.check_collision && MODE != MODE_RESET) {
+    if (live && cfg.check_collision && MODE != MODE_RESET && MODE != MODE_PREFETCH) {
       const double lim = cfg.collision_margin + 1e-6;
       X3 T = identity_x3();
       D3 a0[3], a1[3];
@@ -606,7 +651,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
 #pragma unroll 1
       for (int k = 0; k < lb; k++) {
         double sn, cs;
-        sincos(LDS_STATE ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
+        sincos(LDS_Q ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
         fk_joint(T, k, sn, cs);
         if (k + 1 == la) TA = T;
       }
@@ -737,7 +782,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
   if (wv >= WAVES - G && pe < E && s_env[pe] != -1) {
     const int n = s_env[pe] >= 0 ? s_env[pe] : -2 - s_env[pe];
     double q[6];
-    for (int i = 0; i < 6; i++) q[i] = LDS_STATE ? s_q[i][pe] : joint_of_step<MODE>(P, actions, n, i);
+    for (int i = 0; i < 6; i++) q[i] = LDS_Q ? s_q[i][pe] : joint_of_step<MODE>(P, actions, n, i);
     X3 TE = identity_x3();
 #pragma unroll 1
     for (int k = 0; k < 6; k++) {
@@ -774,6 +819,27 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
         if (cfg.check_collision && ld_new[i] <= cfg.collision_margin) coll = true;
       }
     }
+    if (MODE == MODE_PREFETCH) {
+      // the rest of the record: what RESET would have written into the live state (reach.py:324-325, 680-681; set_velocity)
+      const int key = s_key[pe], sl = key & 1;
+      int rflags = s_flags[pe] & ~COLL_BIT;
+      if (coll) rflags |= URGYM_STATUS_RESET_COLLISION;
+      if (HAS_OBST) {
+        for (int i = 0; i < 5; i++) REC(P, sl, REC_LD + i, n) = ld_new[i];
+        REC(P, sl, REC_QUAT + 0, n) = oq.x; REC(P, sl, REC_QUAT + 1, n) = oq.y; REC(P, sl, REC_QUAT + 2, n) = oq.z; REC(P, sl, REC_QUAT + 3, n) = oq.w;
+        double vel[6] = {0, 0, 0, 0, 0, 0};
+        if (KIND == URGYM_ENV_DYN) {
+          double st[6], en[6];
+          for (int i = 0; i < 6; i++) { st[i] = REC(P, sl, REC_START + i, n); en[i] = REC(P, sl, REC_END + i, n); }
+          dyn_velocity(st, en, cfg.dyn_time_duration, vel);
+        }
+        for (int i = 0; i < 6; i++) REC(P, sl, REC_VEL + i, n) = vel[i];
+      }
+      RECI(P, sl, 1, n) = rflags;
+      __threadfence();
+      RECI(P, sl, 0, n) = key;  // the record is complete
+    }
+    if (MODE != MODE_PREFETCH) {
     // velocity slot of the Dyn observation (reach.py:657): STEP -> the velocity applied in this step; RESET/REFRESH ->
     // the stale ReachDyn.velocity of the previous step, which still sits in the observation buffer
     double vobs[6] = {0, 0, 0, 0, 0, 0};
@@ -794,26 +860,33 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
     }
     // observation row (core.py:252-261; UR5.py:320-325; reach.py:189, 307-308, 653-657)
     const double* ld_obs = (MODE == MODE_STEP) ? ld_old : ld_new;  // step(): link_dist lags one step (core.py:311 vs 316)
-    int p = 0;
-    for (int i = 0; i < 6; i++) row[p++] = ach[i];
-    for (int i = 0; i < 6; i++) row[p++] = (float)q[i];
-    if (KIND == URGYM_ENV_ORI) {
-      for (int i = 0; i < 6; i++) row[p++] = (float)goal[i];
-    } else if (KIND == URGYM_ENV_OBS) {
-      for (int i = 0; i < 3; i++) row[p++] = (float)goal[i];
-      for (int i = 0; i < 6; i++) row[p++] = (float)SOA(B.obst_start, i, n, N);
-      for (int i = 0; i < 5; i++) row[p++] = (float)ld_obs[i];
-    } else {
-      for (int i = 0; i < 6; i++) row[p++] = (float)goal[i];
-      for (int i = 0; i < 3; i++) row[p++] = (float)opos[i];
-      double r_, p_, y_;
-      rpy_from_quat(oq, r_, p_, y_);
-      row[p++] = (float)r_; row[p++] = (float)p_; row[p++] = (float)y_;
-      if (KIND == URGYM_ENV_DYN)  // ReachSta.get_obs has no velocity slot (reach.py:453-457)
-        for (int i = 0; i < 6; i++) row[p++] = (float)vobs[i];
-      for (int i = 0; i < 5; i++) row[p++] = (float)ld_obs[i];
-    }
-    for (int i = 0; i < GD; i++) { row[OD + i] = ach[i]; row[OD + GD + i] = (float)goal[i]; }
+    auto write_row = [&](const float* ach_, const double* q_, const double* goal_, const double* obst6_, const double* opos_, Q4 oq_,
+                         const double* vobs_, const double* ld_) {
+      int p = 0;
+      for (int i = 0; i < 6; i++) row[p++] = ach_[i];
+      for (int i = 0; i < 6; i++) row[p++] = (float)q_[i];
+      if (KIND == URGYM_ENV_ORI) {
+        for (int i = 0; i < 6; i++) row[p++] = (float)goal_[i];
+      } else if (KIND == URGYM_ENV_OBS) {
+        for (int i = 0; i < 3; i++) row[p++] = (float)goal_[i];
+        for (int i = 0; i < 6; i++) row[p++] = (float)obst6_[i];
+        for (int i = 0; i < 5; i++) row[p++] = (float)ld_[i];
+      } else {
+        for (int i = 0; i < 6; i++) row[p++] = (float)goal_[i];
+        for (int i = 0; i < 3; i++) row[p++] = (float)opos_[i];
+        double r_, p_, y_;
+        rpy_from_quat(oq_, r_, p_, y_);
+        row[p++] = (float)r_; row[p++] = (float)p_; row[p++] = (float)y_;
+        if (KIND == URGYM_ENV_DYN)  // ReachSta.get_obs has no velocity slot (reach.py:453-457)
+          for (int i = 0; i < 6; i++) row[p++] = (float)vobs_[i];
+        for (int i = 0; i < 5; i++) row[p++] = (float)ld_[i];
+      }
+      for (int i = 0; i < GD; i++) { row[OD + i] = ach_[i]; row[OD + GD + i] = (float)goal_[i]; }
+    };
+    double obst6[6] = {0, 0, 0, 0, 0, 0};
+    if (KIND == URGYM_ENV_OBS)
+      for (int i = 0; i < 6; i++) obst6[i] = SOA(B.obst_start, i, n, N);
+    write_row(ach, q, goal, obst6, opos, oq, vobs, ld_obs);
 
     // is_success on the float32 achieved goal vs the float64 goal (reach.py:212-215, 348-350, 755-758)
     double dx = (double)ach[0] - goal[0], dy = (double)ach[1] - goal[1], dz = (double)ach[2] - goal[2];
@@ -876,8 +949,61 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       B.is_success[n] = info_success ? 1 : 0;
       B.collision[n] = coll ? 1 : 0;
       if (cfg.auto_reset && (terminated || truncated)) {
-        int slot = atomicAdd(&B.done_count[P.pp], 1);
-        B.done_list[slot] = n;
+        bool consumed = false;
+        if (P.prefetch) {
+          // ---- inline auto-reset from the prefetched record of the env's next episode (valid iff it was computed for
+          // exactly this episode id): what env_kernel<RESET> would do, minus the search.
+          const int ecur = B.episode_id[n], sl = ecur & 1;
+          if (RECI(P, sl, 0, n) == ecur) {
+            consumed = true;
+            // the step's row is the terminal observation
+            for (int i = 0; i < OD; i++) B.final_observation[(size_t)n * OD + i] = row[i];
+            for (int i = 0; i < GD; i++) {
+              B.final_achieved_goal[(size_t)n * GD + i] = row[OD + i];
+              B.final_desired_goal[(size_t)n * GD + i] = row[OD + GD + i];
+            }
+            double g2[6], st2[6], ld2[5] = {0, 0, 0, 0, 0}, v2[6] = {0, 0, 0, 0, 0, 0}, q2[6], op2[3] = {0, 0, 0};
+            Q4 oq2{0, 0, 0, 1};
+            for (int i = 0; i < 6; i++) { g2[i] = REC(P, sl, REC_GOAL + i, n); st2[i] = REC(P, sl, REC_START + i, n); q2[i] = cfg.neutral_q[i]; }
+            for (int i = 0; i < 6; i++) { SOA(B.goal, i, n, N) = g2[i]; SOA(B.q, i, n, N) = q2[i]; }
+            if (HAS_OBST) {
+              for (int i = 0; i < 6; i++) {
+                SOA(B.obst_start, i, n, N) = st2[i];
+                SOA(B.obst_end, i, n, N) = REC(P, sl, REC_END + i, n);
+                SOA(B.obst_vel, i, n, N) = REC(P, sl, REC_VEL + i, n);
+              }
+              oq2 = Q4{REC(P, sl, REC_QUAT + 0, n), REC(P, sl, REC_QUAT + 1, n), REC(P, sl, REC_QUAT + 2, n), REC(P, sl, REC_QUAT + 3, n)};
+              for (int i = 0; i < 3; i++) { op2[i] = st2[i]; SOA(B.obst_pos, i, n, N) = st2[i]; }
+              SOA(B.obst_quat, 0, n, N) = oq2.x; SOA(B.obst_quat, 1, n, N) = oq2.y; SOA(B.obst_quat, 2, n, N) = oq2.z; SOA(B.obst_quat, 3, n, N) = oq2.w;
+              for (int i = 0; i < 5; i++) { ld2[i] = REC(P, sl, REC_LD + i, n); SOA(B.link_dist, i, n, N) = ld2[i]; }
+              // Dyn: the stale ReachDyn.velocity in the reset observation is the float32 value of this step's row
+              if (KIND == URGYM_ENV_DYN)
+                for (int i = 0; i < 6; i++) v2[i] = (double)row[24 + i];
+            }
+            B.step_count[n] = 0;
+            B.episode_id[n] = ecur + 1;
+            flags |= RECI(P, sl, 1, n);
+            // reset observation: the neutral pose's end-effector frame
+            X3 TN = identity_x3();
+#pragma unroll 1
+            for (int k = 0; k < 6; k++) {
+              double sn, cs;
+              sincos(q2[k], &sn, &cs);
+              fk_joint(TN, k, sn, cs);
+            }
+            double nr, np_, ny;
+            rpy_from_quat(rot_to_quat(TN.r), nr, np_, ny);
+            float ach2[6] = {(float)TN.t.x, (float)TN.t.y, (float)TN.t.z, (float)nr, (float)np_, (float)ny};
+            write_row(ach2, q2, g2, st2, op2, oq2, v2, ld2);
+            // the slot is free again: its next occupant is the episode after next
+            const int pos = atomicAdd(P.rcount, 1);
+            if (pos < P.rcap) P.rlist[pos] = make_int2(n, ecur + 2);
+          }
+        }
+        if (!consumed) {
+          int slot = atomicAdd(&B.done_count[P.pp], 1);
+          B.done_list[slot] = n;
+        }
       }
     } else {
       // reset / refresh: fresh link_dist == last_dist (reach.py:324-325, 680-681, 711-713), obstacle pose + velocity
@@ -896,6 +1022,11 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       if (MODE == MODE_RESET) {
         B.step_count[n] = 0;
         if (coll) flags |= URGYM_STATUS_RESET_COLLISION;
+        if (P.prefetch) {  // records of the next two episodes of this env (refilled by the PREFETCH launch that follows)
+          const int k0 = s_key[pe];
+          const int pos = atomicAdd(P.rcount, 2);
+          if (pos + 1 < P.rcap) { P.rlist[pos] = make_int2(n, k0); P.rlist[pos + 1] = make_int2(n, k0 + 1); }
+        }
         if (!P.copy_final) {
           B.reward[n] = 0.f; B.terminated[n] = 0; B.truncated[n] = 0;
           B.is_success[n] = succ ? 1 : 0;
@@ -907,6 +1038,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       }
     }
     if (flags) atomicOr(&B.status[n], flags);
+    }  // MODE != MODE_PREFETCH
   }
   STAMP_TIME(7);
   STAMP(9, __builtin_amdgcn_s_memrealtime());
@@ -922,7 +1054,7 @@ __global__ void __launch_bounds__(THREADS, (MODE == MODE_STEP ? 3 : 2)) env_kern
       B.desired_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + GD + (i % GD)];
     }
     if (blockIdx.x == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
-  } else {
+  } else if (MODE != MODE_PREFETCH) {
     const int cnt = min(E, list_count - (int)blockIdx.x * E);
     for (int i = tid; i < cnt * OD; i += THREADS) {
       const int e = i / OD;
@@ -1005,8 +1137,22 @@ struct Handle {
   // timing
   bool timing = false;
   std::vector<hipEvent_t> ev;  // pairs: [2i] start, [2i+1] stop ; kind in ev_kind
-  std::vector<int> ev_kind;    // 0 = step kernel, 1 = reset kernel
+  std::vector<int> ev_kind;    // 0 = step kernel, 1 = reset kernel(s) on the caller's stream, 2 = overlapped refill
   size_t ev_used = 0;
+  double last_refill_us = 0.0;
+  // prefetched episode records (DESIGN.md "auto-reset off the critical path")
+  bool prefetch = false;
+  double* d_rec = nullptr;      // [2][REC_FIELDS][N]
+  int32_t* d_reci = nullptr;    // [2][2][N]
+  int2* d_rl[3] = {nullptr, nullptr, nullptr};  // refill lists: two alternating asynchronous ones, one synchronous
+  int rl_cap[3] = {0, 0, 0};
+  int* d_rcount = nullptr;      // their counters
+  hipStream_t rs = nullptr;     // side stream of the asynchronous refills
+  hipEvent_t ev_step = nullptr, ev_refill = nullptr;
+  bool refill_pending = false;
+  int parity = 0;
+  uint64_t rec_seed = 0;
+  bool rec_seed_valid = false;
 };
 thread_local char g_err[512] = {0};
 
@@ -1086,14 +1232,23 @@ KParams make_params(Handle* h, int copy_final) {
   P.pp = h->pp;
   P.copy_final = copy_final;
   P.envs = GROUP;
+  P.rec_d = h->d_rec;
+  P.rec_i = h->d_reci;
+  P.rlist = nullptr;
+  P.rcount = nullptr;
+  P.rcap = 0;
+  P.rzero = nullptr;
+  P.prefetch = 0;
   return P;
 }
 
 template <int MODE>
-void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s) {
-  envs = envs < 1 ? 1 : (envs > MAX_ENVS ? MAX_ENVS : envs);   // the kernel's LDS is sized for MAX_ENVS
+void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s, long items = -1) {
+  const int cap = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : MAX_ENVS;
+  envs = envs < 1 ? 1 : (envs > cap ? cap : envs);              // the kernel's LDS is sized for that many
   P.envs = envs;
-  dim3 grid((h->cfg.num_envs + envs - 1) / envs), block(THREADS);
+  if (items < 0) items = h->cfg.num_envs;                       // list-driven launches: an upper bound of the list length
+  dim3 grid((unsigned)((items + envs - 1) / envs)), block(THREADS);
   switch (h->cfg.env_kind) {
     case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
     case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE>), grid, block, 0, s, P, actions); break;
@@ -1128,15 +1283,68 @@ int check_bound(Handle* h) {
   return URGYM_OK;
 }
 
+void release_prefetch(Handle* h) {
+  if (h->rs) { hipStreamSynchronize(h->rs); hipStreamDestroy(h->rs); h->rs = nullptr; }
+  if (h->ev_step) { hipEventDestroy(h->ev_step); h->ev_step = nullptr; }
+  if (h->ev_refill) { hipEventDestroy(h->ev_refill); h->ev_refill = nullptr; }
+  if (h->d_rec) { hipFree(h->d_rec); h->d_rec = nullptr; }
+  if (h->d_reci) { hipFree(h->d_reci); h->d_reci = nullptr; }
+  for (int i = 0; i < 3; i++)
+    if (h->d_rl[i]) { hipFree(h->d_rl[i]); h->d_rl[i] = nullptr; }
+  if (h->d_rcount) { hipFree(h->d_rcount); h->d_rcount = nullptr; }
+}
+
+// list `which` (0 / 1: asynchronous, 2: synchronous) as the refill list of a launch
+void use_list(Handle* h, KParams& P, int which) {
+  P.rlist = h->d_rl[which];
+  P.rcount = h->d_rcount + which;
+  P.rcap = h->rl_cap[which];
+  P.prefetch = 1;
+}
+
 int do_step(Handle* h, const float* actions, hipStream_t s) {
   KParams P = make_params(h, 1);
+  const bool pf = h->prefetch && h->cfg.auto_reset;
+  const int par = h->parity;
+  if (pf) {
+    use_list(h, P, par);            // (its counter was armed by the previous step's fallback launch, see below)
+    P.rzero = h->d_rcount + 2;      // the step kernel arms the synchronous list for this step's fallback launch
+  }
   int slot = time_begin(h, 0, s);
   launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
   time_end(h, slot, s);
-  if (h->cfg.auto_reset) {
+  if (h->cfg.auto_reset && !pf) {
     slot = time_begin(h, 1, s);
     launch_mode<MODE_RESET>(h, P, nullptr, h->reset_envs, s);  // ~1 % of the envs per step: small workgroups, many CUs
     time_end(h, slot, s);
+  }
+  if (pf) {
+    // Finished envs were reset inline from their prefetched records.  What is left on this stream is the fallback for envs
+    // whose record was not valid (first use, set_state, a refill that did not fit): normally two empty launches.  The
+    // refill of the PREVIOUS step ran under this step's kernel; it must be complete before any record is rewritten here and
+    // before its list is reused by the next step.
+    if (h->refill_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_refill, 0));
+    slot = time_begin(h, 1, s);
+    KParams Pr = P;
+    use_list(h, Pr, 2);
+    Pr.rzero = h->d_rcount + (par ^ 1);  // the refill that read the other asynchronous list is complete: arm it for the next step
+    launch_mode<MODE_RESET>(h, Pr, nullptr, GROUP, s);
+    Pr.rzero = nullptr;
+    launch_mode<MODE_PREFETCH>(h, Pr, nullptr, 8, s, 4096);   // bounded: entries beyond it stay stale and fall back again
+    time_end(h, slot, s);
+    // the refill of the slots consumed in this step runs on the side stream, under the next step's kernel
+    HIP_TRY(h, hipEventRecord(h->ev_step, s));
+    HIP_TRY(h, hipStreamWaitEvent(h->rs, h->ev_step, 0));
+    KParams Pa = P;
+    use_list(h, Pa, par);
+    Pa.rzero = nullptr;
+    slot = time_begin(h, 2, h->rs);
+    // few, dense workgroups: this launch has a whole step to finish, what matters is that it leaves the CUs to the step kernel
+    launch_mode<MODE_PREFETCH>(h, Pa, nullptr, PREFETCH_MAX_ENVS, h->rs, h->rl_cap[par]);
+    time_end(h, slot, h->rs);
+    HIP_TRY(h, hipEventRecord(h->ev_refill, h->rs));
+    h->refill_pending = true;
+    h->parity ^= 1;
   }
   h->pp ^= 1;
   HIP_TRY(h, hipGetLastError());
@@ -1148,10 +1356,23 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count + h->pp, 0, sizeof(int32_t), s));
   hipLaunchKernelGGL(build_list_kernel, dim3((N + 255) / 256), dim3(256), 0, s, mask, N, h->buf.done_list, h->buf.done_count + h->pp);
   KParams P = make_params(h, 0);
-  if (mode == MODE_RESET)
+  if (mode == MODE_RESET) {
+    const bool pf = h->prefetch && h->cfg.auto_reset;
+    if (pf) {
+      if (h->refill_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_refill, 0));
+      if (!h->rec_seed_valid || h->rec_seed != h->seed) {  // records are keyed with the seed: a new one invalidates them all
+        HIP_TRY(h, hipMemsetAsync(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)N, s));
+        h->rec_seed = h->seed;
+        h->rec_seed_valid = true;
+      }
+      HIP_TRY(h, hipMemsetAsync(h->d_rcount, 0, 4 * sizeof(int), s));  // (nothing is in flight here)
+      use_list(h, P, 2);
+    }
     launch_mode<MODE_RESET>(h, P, nullptr, GROUP, s);
-  else
+    if (pf) launch_mode<MODE_PREFETCH>(h, P, nullptr, 8, s, h->rl_cap[2]);  // the next two episodes of every env just reset
+  } else {
     launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP, s);
+  }
   // leave the consumed counter zeroed so the next step can append to either slot
   HIP_TRY(h, hipMemsetAsync(h->buf.done_count, 0, 2 * sizeof(int32_t), s));
   HIP_TRY(h, hipGetLastError());
@@ -1257,9 +1478,36 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       const int r = atoi(ov);
       if (r >= 1 && r <= MAX_ENVS) h->reset_envs = r;
     }
+    // prefetched episode records: on unless URGYM_PREFETCH=0 (then finished envs are reset by a kernel after each step)
+    // (Ori's reset is a goal draw, no distance query: there the extra launches cost more than the reset kernel they replace)
+    h->prefetch = cfg->env_kind != URGYM_ENV_ORI;
+    if (const char* ov = getenv("URGYM_PREFETCH")) h->prefetch = atoi(ov) != 0;
+    if (h->prefetch) {
+      const size_t nn = (size_t)n;
+      h->rl_cap[0] = h->rl_cap[1] = (int)n;   // at most one entry per env and step: no entry is ever dropped
+      h->rl_cap[2] = (int)(2 * n);
+      hipError_t pe = hipMalloc((void**)&h->d_rec, sizeof(double) * 2 * REC_FIELDS * nn);
+      if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_reci, sizeof(int32_t) * 4 * nn);
+      for (int i = 0; i < 3 && pe == hipSuccess; i++) pe = hipMalloc((void**)&h->d_rl[i], sizeof(int2) * (size_t)h->rl_cap[i]);
+      if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 4);
+      if (pe == hipSuccess) pe = hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * nn);
+      if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 4);
+      if (pe == hipSuccess) pe = hipStreamCreateWithFlags(&h->rs, hipStreamNonBlocking);
+      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming);
+      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_refill, hipEventDisableTiming);
+      if (pe != hipSuccess) {
+        release_prefetch(h);
+        if (h->d_verts64) hipFree(h->d_verts64);
+        if (h->d_recs) hipFree(h->d_recs);
+        if (h->d_dirmap) hipFree(h->d_dirmap);
+        delete h;
+        return fail(nullptr, URGYM_ERR_HIP, "prefetch buffers", pe);
+      }
+    }
     if (getenv("URGYM_VERBOSE"))
       fprintf(stderr, "[urgym] device %d: %d CUs x %d resident step workgroups; N = %ld -> %d envs per step workgroup (%ld workgroups), %d per reset workgroup\n",
               device, cus, per_cu, n, h->step_envs, (n + h->step_envs - 1) / h->step_envs, h->reset_envs);
+    if (getenv("URGYM_VERBOSE")) fprintf(stderr, "[urgym] prefetched episode records: %s\n", h->prefetch ? "on" : "off");
   }
   *handle = h;
   return URGYM_OK;
@@ -1269,6 +1517,7 @@ int urgym_destroy(void* handle) {
   Handle* h = (Handle*)handle;
   if (!h) return URGYM_OK;
   hipSetDevice(h->device);
+  release_prefetch(h);
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
@@ -1287,6 +1536,13 @@ int urgym_bind(void* handle, const urgym_buffers* b) {
     return fail(h, URGYM_ERR_ARG, "urgym_bind: a required buffer pointer is null");
   if (obst && (!b->obst_start || !b->obst_end || !b->obst_pos || !b->obst_quat || !b->obst_vel || !b->link_dist))
     return fail(h, URGYM_ERR_ARG, "urgym_bind: an obstacle buffer pointer is null");
+  if (h->prefetch) {  // records belong to the state that was bound before
+    hipSetDevice(h->device);
+    if (h->rs) hipStreamSynchronize(h->rs);
+    HIP_TRY(h, hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)h->cfg.num_envs));
+    h->refill_pending = false;
+    h->rec_seed_valid = false;
+  }
   h->buf = *b;
   h->bound = true;
   return URGYM_OK;
@@ -1357,8 +1613,8 @@ int urgym_query_timing(void* handle, double* step_us, double* reset_us, int* lau
   Handle* h = (Handle*)handle;
   if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
   if (!h->timing) return fail(h, URGYM_ERR_STATE, "timing not enabled");
-  double acc[2] = {0, 0};
-  int cnt[2] = {0, 0};
+  double acc[3] = {0, 0, 0};
+  int cnt[3] = {0, 0, 0};
   for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
     HIP_TRY(h, hipEventSynchronize(h->ev[i + 1]));
     float ms = 0;
@@ -1369,6 +1625,7 @@ int urgym_query_timing(void* handle, double* step_us, double* reset_us, int* lau
   }
   if (step_us) *step_us = cnt[0] ? acc[0] / cnt[0] : 0.0;
   if (reset_us) *reset_us = cnt[1] ? acc[1] / cnt[1] : 0.0;
+  h->last_refill_us = cnt[2] ? acc[2] / cnt[2] : 0.0;
   if (launches) *launches = cnt[0];
   h->ev_used = 0;
   return URGYM_OK;
@@ -1382,6 +1639,13 @@ int urgym_debug_stamps(unsigned long long* out, int count) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count, 0, hipMemcpyDeviceToHost);
 }
 #endif
+
+int urgym_query_refill_timing(void* handle, double* refill_us) {
+  Handle* h = (Handle*)handle;
+  if (!h || !refill_us) return fail(h, URGYM_ERR_ARG, "urgym_query_refill_timing: null argument");
+  *refill_us = h->last_refill_us;
+  return URGYM_OK;
+}
 
 const char* urgym_last_error(void* handle) {
   Handle* h = (Handle*)handle;

@@ -263,6 +263,9 @@ class UR5ReachVectorEnv:
         """(avg step-kernel us, avg reset-kernel us, #step launches) since the last query — HIP events on the launch stream."""
         a, b, n = C.c_double(), C.c_double(), C.c_int()
         _native.check(self.lib.urgym_query_timing(self._h, C.byref(a), C.byref(b), C.byref(n)), self._h)
+        r = C.c_double()
+        _native.check(self.lib.urgym_query_refill_timing(self._h, C.byref(r)), self._h)
+        self.last_refill_us = r.value  # overlapped refill of prefetched episode records (0 when that path is off)
         return a.value, b.value, n.value
 
 
