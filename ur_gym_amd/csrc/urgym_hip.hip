@@ -99,6 +99,7 @@ struct KParams {
   int rcap;         // capacity of rlist
   int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
   int prefetch;     // 1: STEP resets finished envs inline from valid records; RESET files refill entries
+  float neutral_ach[6];  // end-effector position + Euler angles of the neutral pose, float32 as _get_obs casts them (set at create)
 };
 __device__ __forceinline__ double& REC(const KParams& P, int slot, int f, int n) {
   return P.rec_d[((size_t)slot * REC_FIELDS + f) * P.cfg.num_envs + n];
@@ -983,17 +984,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
             B.step_count[n] = 0;
             B.episode_id[n] = ecur + 1;
             flags |= RECI(P, sl, 1, n);
-            // reset observation: the neutral pose's end-effector frame
-            X3 TN = identity_x3();
-#pragma unroll 1
-            for (int k = 0; k < 6; k++) {
-              double sn, cs;
-              sincos(q2[k], &sn, &cs);
-              fk_joint(TN, k, sn, cs);
-            }
-            double nr, np_, ny;
-            rpy_from_quat(rot_to_quat(TN.r), nr, np_, ny);
-            float ach2[6] = {(float)TN.t.x, (float)TN.t.y, (float)TN.t.z, (float)nr, (float)np_, (float)ny};
+            // reset observation: the neutral pose's end-effector frame (a constant, evaluated once at urgym_create by the
+            // same device code the RESET kernel runs)
+            float ach2[6];
+            for (int i = 0; i < 6; i++) ach2[i] = P.neutral_ach[i];
             write_row(ach2, q2, g2, st2, op2, oq2, v2, ld2);
             // the slot is free again: its next occupant is the episode after next
             const int pos = atomicAdd(P.rcount, 1);
@@ -1072,6 +1066,20 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   }
 }
 
+// end-effector pose of a joint vector exactly as P4 derives it (urgym_create evaluates the neutral pose once)
+__global__ void ee_pose_kernel(const double* q, float* out) {
+  X3 TE = identity_x3();
+  for (int k = 0; k < 6; k++) {
+    double sn, cs;
+    sincos(q[k], &sn, &cs);
+    fk_joint(TE, k, sn, cs);
+  }
+  double er, ep, ey;
+  rpy_from_quat(rot_to_quat(TE.r), er, ep, ey);
+  out[0] = (float)TE.t.x; out[1] = (float)TE.t.y; out[2] = (float)TE.t.z;
+  out[3] = (float)er; out[4] = (float)ep; out[5] = (float)ey;
+}
+
 // unit probe: one closest-distance query per lane through the very same device GJK (tests only; not on the hot path)
 __global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, const double* par_a, const double* pose_a,
                                      const int* type_b, const double* par_b, const double* pose_b, double threshold,
@@ -1142,6 +1150,7 @@ struct Handle {
   double last_refill_us = 0.0;
   // prefetched episode records (DESIGN.md "auto-reset off the critical path")
   bool prefetch = false;
+  float neutral_ach[6] = {0, 0, 0, 0, 0, 0};
   double* d_rec = nullptr;      // [2][REC_FIELDS][N]
   int32_t* d_reci = nullptr;    // [2][2][N]
   int2* d_rl[3] = {nullptr, nullptr, nullptr};  // refill lists: two alternating asynchronous ones, one synchronous
@@ -1239,6 +1248,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.rcap = 0;
   P.rzero = nullptr;
   P.prefetch = 0;
+  for (int i = 0; i < 6; i++) P.neutral_ach[i] = h->neutral_ach[i];
   return P;
 }
 
@@ -1492,6 +1502,19 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 4);
       if (pe == hipSuccess) pe = hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * nn);
       if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 4);
+      if (pe == hipSuccess) {  // the neutral pose's end-effector frame, by the device code itself
+        double* dq = nullptr;
+        float* dout = nullptr;
+        pe = hipMalloc((void**)&dq, sizeof(double) * 6);
+        if (pe == hipSuccess) pe = hipMalloc((void**)&dout, sizeof(float) * 6);
+        if (pe == hipSuccess) pe = hipMemcpy(dq, cfg->neutral_q, sizeof(double) * 6, hipMemcpyHostToDevice);
+        if (pe == hipSuccess) {
+          hipLaunchKernelGGL(ee_pose_kernel, dim3(1), dim3(1), 0, 0, dq, dout);
+          pe = hipMemcpy(h->neutral_ach, dout, sizeof(float) * 6, hipMemcpyDeviceToHost);
+        }
+        if (dq) hipFree(dq);
+        if (dout) hipFree(dout);
+      }
       if (pe == hipSuccess) pe = hipStreamCreateWithFlags(&h->rs, hipStreamNonBlocking);
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming);
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_refill, hipEventDisableTiming);
