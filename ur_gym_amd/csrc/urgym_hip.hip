@@ -1515,7 +1515,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
         if (dq) hipFree(dq);
         if (dout) hipFree(dout);
       }
-      if (pe == hipSuccess) pe = hipStreamCreateWithFlags(&h->rs, hipStreamNonBlocking);
+      if (pe == hipSuccess) {  // lowest priority: the refill should take the slots the step kernel leaves free, not compete for them
+        int least = 0, greatest = 0;
+        hipDeviceGetStreamPriorityRange(&least, &greatest);
+        pe = hipStreamCreateWithPriority(&h->rs, hipStreamNonBlocking, least);
+      }
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming);
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_refill, hipEventDisableTiming);
       if (pe != hipSuccess) {
