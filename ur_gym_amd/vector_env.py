@@ -157,10 +157,14 @@ class UR5ReachVectorEnv:
             raise ValueError(f"actions must have shape ({self.num_envs}, 6), got {tuple(a.shape)}")
         _native.check(self.lib.urgym_step(self._h, C.c_void_p(a.data_ptr()), self._stream()), self._h)
         b = self.buf
-        terminated, truncated = b["terminated"].bool(), b["truncated"].bool()
-        info = {"is_success": b["is_success"].bool(), "collision": b["collision"].bool()}
+        # the flag buffers hold 0 / 1 bytes: reinterpret them as bool instead of launching a conversion kernel per flag
+        terminated, truncated = b["terminated"].view(torch.bool), b["truncated"].view(torch.bool)
+        info = {"is_success": b["is_success"].view(torch.bool), "collision": b["collision"].view(torch.bool)}
+        if self.copy_obs:  # like the observations: private copies on request, zero-copy views of the live buffers otherwise
+            terminated, truncated = terminated.clone(), truncated.clone()
+            info = {k: v.clone() for k, v in info.items()}
         if self.cfg.auto_reset:
-            info["_final_observation"] = terminated | truncated
+            info = _LazyInfo(info, {"_final_observation": lambda: terminated | truncated})  # (a kernel launch only if somebody looks)
             info["final_observation"] = {"observation": b["final_observation"], "achieved_goal": b["final_achieved_goal"],
                                          "desired_goal": b["final_desired_goal"]}
         reward = b["reward"].clone() if self.copy_obs else b["reward"]
@@ -267,6 +271,50 @@ class UR5ReachVectorEnv:
         _native.check(self.lib.urgym_query_refill_timing(self._h, C.byref(r)), self._h)
         self.last_refill_us = r.value  # overlapped refill of prefetched episode records (0 when that path is off)
         return a.value, b.value, n.value
+
+
+class _LazyInfo(dict):
+    """info dict whose derived entries are computed on first access: a `step()` that nobody inspects launches no extra kernel."""
+
+    def __init__(self, base, lazy):
+        super().__init__(base)
+        self._lazy = dict(lazy)
+
+    def _materialise(self):
+        for k in list(self._lazy):
+            dict.__setitem__(self, k, self._lazy.pop(k)())
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            value = self._lazy.pop(key)()
+            dict.__setitem__(self, key, value)
+            return value
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        return dict.__len__(self) + len(self._lazy)
 
 
 def make_vec(env_id, num_envs=1, **kwargs):
