@@ -138,3 +138,18 @@ def test_two_rank_gloo_sharding_and_gather():
         assert ids == [float(i) for i in range(8)]  # every rank sees all shards in global order
         assert slowest == 2.0                       # max over ranks
         assert seed == 5 + 1000 * rank
+
+
+def test_lazy_info_dict_semantics():
+    """VectorEnv.step returns derived info entries lazily (no kernel launch unless read); it must still behave like a dict."""
+    from ur_gym_amd.vector_env import _LazyInfo
+
+    calls = []
+    info = _LazyInfo({"is_success": 1}, {"_final_observation": lambda: (calls.append(1), 7)[1]})
+    assert "_final_observation" in info and len(info) == 2 and not calls
+    assert info.get("missing", 3) == 3 and not calls
+    assert info["_final_observation"] == 7 and info["_final_observation"] == 7 and calls == [1]
+    other = _LazyInfo({"a": 1}, {"b": lambda: 2})
+    assert dict(other) == {"a": 1, "b": 2} and sorted(other) == ["a", "b"] and list(other.values()) == [1, 2]
+    with pytest.raises(KeyError):
+        info["nope"]
