@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
+  constexpr int EE_BIT = 1 << 29;  // STEP: the per-env phase has already stored the end-effector pose of this step (P4 reads it back)
   const XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
   static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
@@ -599,6 +600,17 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
             if (segseg_dist(a0[A - 1], a1[A - 1], b0, b1) - c_tab.capsule[A - 1][6] - rb <= lim) pairs |= 1u << self_pair_bit(A, link);
           }
         }
+      }
+      if (MODE == MODE_STEP) {
+        // T is now the end-effector frame (link 6 == ee_link 7): read it out here, in the shadow of the other waves' queries,
+        // instead of repeating the FK in P4 on the workgroup's critical path.  This very lane is also the env's P4 lane; the
+        // six float32 values are parked in the env's observation row (their final place) and read back there.
+        double er, ep, ey;
+        rpy_from_quat(rot_to_quat(T.r), er, ep, ey);
+        float* orow = B.observation + (size_t)n * OD;
+        orow[0] = (float)T.t.x; orow[1] = (float)T.t.y; orow[2] = (float)T.t.z;
+        orow[3] = (float)er; orow[4] = (float)ep; orow[5] = (float)ey;
+        atomicOr(&s_flags[e], EE_BIT);
       }
     }
     s_pairs[e] = pairs;
@@ -784,12 +796,15 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     const int n = s_env[pe] >= 0 ? s_env[pe] : -2 - s_env[pe];
     double q[6];
     for (int i = 0; i < 6; i++) q[i] = LDS_Q ? s_q[i][pe] : joint_of_step<MODE>(P, actions, n, i);
+    const bool ee_ready = (MODE == MODE_STEP) && (s_flags[pe] & EE_BIT);
     X3 TE = identity_x3();
+    if (!ee_ready) {
 #pragma unroll 1
-    for (int k = 0; k < 6; k++) {
-      double sn, cs;
-      sincos(q[k], &sn, &cs);
-      fk_joint(TE, k, sn, cs);
+      for (int k = 0; k < 6; k++) {
+        double sn, cs;
+        sincos(q[k], &sn, &cs);
+        fk_joint(TE, k, sn, cs);
+      }
     }
     double opos[3] = {0, 0, 0};
     Q4 oq{0, 0, 0, 1};
@@ -802,13 +817,17 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       }
     }
     const int step_count = B.step_count[n];
-    Q4 eq = rot_to_quat(TE.r);
-    double er, ep, ey;
-    rpy_from_quat(eq, er, ep, ey);
     float* row = &s_out[pe * 47];
     float ach[6];
-    ach[0] = (float)TE.t.x; ach[1] = (float)TE.t.y; ach[2] = (float)TE.t.z;
-    ach[3] = (float)er; ach[4] = (float)ep; ach[5] = (float)ey;
+    if (ee_ready) {
+      for (int i = 0; i < 6; i++) ach[i] = B.observation[(size_t)n * OD + i];
+    } else {
+      Q4 eq = rot_to_quat(TE.r);
+      double er, ep, ey;
+      rpy_from_quat(eq, er, ep, ey);
+      ach[0] = (float)TE.t.x; ach[1] = (float)TE.t.y; ach[2] = (float)TE.t.z;
+      ach[3] = (float)er; ach[4] = (float)ep; ach[5] = (float)ey;
+    }
     double goal[6];
     for (int i = 0; i < 6; i++) goal[i] = SOA(B.goal, i, n, N);
     double ld_old[5] = {0, 0, 0, 0, 0}, ld_new[5] = {0, 0, 0, 0, 0};
@@ -823,7 +842,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if (MODE == MODE_PREFETCH) {
       // the rest of the record: what RESET would have written into the live state (reach.py:324-325, 680-681; set_velocity)
       const int key = s_key[pe], sl = key & 1;
-      int rflags = s_flags[pe] & ~COLL_BIT;
+      int rflags = s_flags[pe] & ~(COLL_BIT | EE_BIT);
       if (coll) rflags |= URGYM_STATUS_RESET_COLLISION;
       if (HAS_OBST) {
         for (int i = 0; i < 5; i++) REC(P, sl, REC_LD + i, n) = ld_new[i];
@@ -901,7 +920,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       th = angular_distance(a3, goal + 3);
       succ = (d < cfg.distance_threshold) && (th < cfg.ori_threshold);
     }
-    int flags = s_flags[pe] & ~COLL_BIT;
+    int flags = s_flags[pe] & ~(COLL_BIT | EE_BIT);
     if (MODE == MODE_STEP) {
       bool terminated = succ || coll;                 // core.py:313
       bool info_success = terminated ? !coll : false; // core.py:315
