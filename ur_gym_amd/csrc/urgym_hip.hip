@@ -626,8 +626,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // ---- P2 + P3: all closest-distance work of the workgroup goes through ONE inlined, resumable GJK body, fed from a
   //      work pool so that no lane waits for the slowest query of its wave:
   //   obstacle tickets t in [0, 5E): exact distance hull(link 2 + t / E) <-> obstacle cylinder of env slot t % E
-  //             (pyb_setup.py:439-456; also the obstacle rule of check_collision).  The first 320 tickets are the lanes'
-  //             own (link uniform per wave), the rest (G = 2) is drawn from s_ticket as lanes finish.
+  //             (pyb_setup.py:439-456; also the obstacle rule of check_collision).  The first 256 tickets are the lanes'
+  //             own (with E = 64: one hull per wave), the rest (E > 51) is drawn from s_ticket as lanes finish.
   //   pair bits: the culling survivors of P1, boolean "closer than the margin?" queries, claimed bit by bit once the
   //             tickets are gone.
   //   A lane advances its query by one GJK iteration per loop trip; a finished lane draws the next item.
@@ -762,7 +762,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         }
       }
       const bool more_tickets = s_ticket < n_tickets, more_pairs = s_pending > 0;  // wave-uniform reads
-      // drawing an item costs the whole wave a set-up (FK + operands) and a seed pass of the hill climb, so idle lanes
+      // drawing an item costs the whole wave a set-up (FK + operands), so idle lanes
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
       const int idle_lanes = __popcll(__ballot(!busy));
       if (!busy && (idle_lanes >= REFILL_MIN || idle_lanes == 64)) {
@@ -1466,7 +1466,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
   }
   // Envs per step workgroup (E).  Measured on MI355X (DESIGN.md "launch geometry"): the kernel is bound by the latency of
-  // the GJK iteration chain, a round of resident workgroups takes ~(300 + 2.8 E) us almost independently of how full the
+  // the GJK iteration chain, a round of resident workgroups takes about the same time almost independently of how full the
   // chip is, and E = 64 (one hull per wave) is the most efficient shape.  So:
   //   * N fits one round: the smallest power of two E >= 8 whose ceil(N / E) workgroups are all resident at once;
   //   * N needs two rounds of 64: E = ceil(N / (2 * slots)) so that the second round is a full one (65536 -> 43);
