@@ -1483,8 +1483,15 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP>, THREADS, 0); break;
     }
     if (oe != hipSuccess || per_cu < 1) per_cu = 3;
-    const long slots = (long)cus * per_cu;
+    long slots = (long)cus * per_cu;
     const long n = cfg->num_envs;
+    // prefetched episode records (below): the refill of ~2 % of the envs runs beside the step kernel, 32 envs per workgroup
+    bool want_prefetch = cfg->env_kind != URGYM_ENV_ORI;
+    if (const char* ov = getenv("URGYM_PREFETCH")) want_prefetch = atoi(ov) != 0;
+    if (want_prefetch && cfg->auto_reset) {
+      const long refill = n / 1600;
+      slots -= refill < slots / 8 ? refill : slots / 8;
+    }
     long envs = GROUP;
     if (n <= slots * GROUP) {
       envs = 8;
@@ -1509,8 +1516,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     }
     // prefetched episode records: on unless URGYM_PREFETCH=0 (then finished envs are reset by a kernel after each step)
     // (Ori's reset is a goal draw, no distance query: there the extra launches cost more than the reset kernel they replace)
-    h->prefetch = cfg->env_kind != URGYM_ENV_ORI;
-    if (const char* ov = getenv("URGYM_PREFETCH")) h->prefetch = atoi(ov) != 0;
+    h->prefetch = want_prefetch;
     if (h->prefetch) {
       const size_t nn = (size_t)n;
       h->rl_cap[0] = h->rl_cap[1] = (int)n;   // at most one entry per env and step: no entry is ever dropped
