@@ -13,5 +13,6 @@ run sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU 
 run sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1
+# the kernel trace runs the DEFAULT bench command (same steps / warm-up), so that its average kernel duration is comparable with bench.py's own
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
 find $OUT -name "*.csv" -size +20M -delete
