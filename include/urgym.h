@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define URGYM_ABI_VERSION 1
+#define URGYM_ABI_VERSION 2
 
 /* env kinds = the reference's registered ids (UR_gym/__init__.py:19-42, UR_gym/envs/ur_tasks.py:37-90) */
 enum {
@@ -57,13 +57,29 @@ enum {
   URGYM_GJK_START_GUIDED = 1,
 };
 
+/* What task.link_dist (the five "link distance" slots of the Obs/Sta/Dyn observation and the distance-change reward) measures.
+ * OBSTACLE : links 2..6 vs the obstacle -- PyBullet.get_link_distances as it stands (pyb_setup.py:439-456).  Default.
+ * WORKBENCH: per link the minimum over obstacle, table and track -- what the docstring of get_link_distances still says
+ *            ("the distance between workbench, obstacle and UR5") and what the reference's code evidently did when its
+ *            UR5ObsReach-v1 / UR5StaReach-v1 checkpoints were trained (Sep 2023): the observations stored inside
+ *            Trained_Models/Trained_{Obs,Sta}/best_model.zip are reproduced to 1e-7 by this rule and not by OBSTACLE
+ *            (tests/test_reference_pins.py).  Needed to replay those two checkpoints (tests/test_closed_loop.py). */
+enum {
+  URGYM_LINK_DIST_OBSTACLE = 0,
+  URGYM_LINK_DIST_WORKBENCH = 1,
+};
+
 /* bits of the per-env status word (device-side anomalies; SURVEY.md §5 "failure detection") */
 enum {
   URGYM_STATUS_NAN = 1,              /* a NaN reached the reward/obs (utils.py:65-67 prints in the reference) */
   URGYM_STATUS_RESET_EXHAUSTED = 2,  /* rejection sampling hit max_reset_tries (reach.py:668-675 loops forever) */
   URGYM_STATUS_RESET_COLLISION = 4,  /* "Collision after reset, this should not happen" (reach.py:682-683) */
-  URGYM_STATUS_PENETRATION = 8,      /* a core-shape overlap was clamped (no EPA depth; DESIGN.md "deviations") */
-  URGYM_STATUS_GJK_ITER = 16,        /* GJK hit its iteration cap */
+  URGYM_STATUS_PENETRATION = 8,      /* informational: a link_dist that was consumed is a penetration depth (negative) */
+  URGYM_STATUS_GJK_ITER = 16,        /* GJK / EPA hit its iteration cap */
+  URGYM_STATUS_JOINT_LIMIT = 32,     /* a joint was commanded past its URDF limit (ur5e.urdf:237-277: elbow +-pi, others +-2pi).
+                                        The reference teleports joints with resetJointState, which does not clamp, but Bullet's
+                                        limit constraints then act during stepSimulation: from here on the kinematic model of this
+                                        build is outside the regime it was checked in. */
 };
 
 /* One POD config struct: every constant the reference hard-codes in its task constructors. */
@@ -76,6 +92,8 @@ typedef struct urgym_config {
   int32_t max_reset_tries;   /* bound on the reference's unbounded rejection loop */
   int32_t dyn_motion_steps;  /* reach.py:735 -> 25 */
   int32_t gjk_start;         /* URGYM_GJK_START_*: first separating axis of every link query (default BULLET) */
+  int32_t link_dist_scope;   /* URGYM_LINK_DIST_*: what task.link_dist measures (default OBSTACLE = the reference as it stands) */
+  int32_t reserved0;         /* keeps the doubles 8-byte aligned; must be 0 */
   double action_scale;       /* UR5.py:276,314: pi*0.1 is applied as two float32 products; kept for reporting */
   double dt;                 /* pyb_setup.py:40,47-50: 20 substeps / 500 Hz = 0.04 s */
   double distance_threshold; /* reach.py:148/246/590 -> 0.05 */
@@ -104,7 +122,10 @@ typedef struct urgym_buffers {
   double* obst_end;   /* [6][N] obstacle end xyz+rpy    (Dyn; Sta: all-zero = static obstacle, reach.py:306) */
   double* obst_pos;   /* [3][N] current obstacle position (Bullet base position) */
   double* obst_quat;  /* [4][N] current obstacle orientation xyzw */
-  double* obst_vel;   /* [6][N] per-episode (v, omega) applied while step_count < dyn_motion_steps */
+  double* obst_vel;   /* [9][N] rows 0..5: per-episode twist (v, omega) that set_velocity (reach.py:728-753) re-applies while
+                         step_count < dyn_motion_steps; rows 6..8: the base displacement that twist produces in ONE env step
+                         (20 Bullet sub-steps in which the linear velocity drifts by h * omega x v) --
+                         derived at reset / refresh; a caller that edits rows 0..5 must call urgym_refresh */
   double* link_dist;  /* [5][N] task.link_dist == task.last_dist (reach.py:680-681,780-782) */
   int32_t* step_count;/* [N] ReachDyn.step_num == TimeLimit._elapsed_steps */
   int32_t* episode_id;/* [N] number of resets so far (RNG counter) */
@@ -169,6 +190,12 @@ int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream);
  * Used by the parity tests to reach the hull<->box and hull<->hull paths directly. */
 int urgym_probe_closest(void* handle, int count, const int* type_a, const double* par_a, const double* pose_a, const int* type_b,
                         const double* par_b, const double* pose_b, double threshold, double* out_dist, int* out_info, void* stream);
+
+/* Unit probe of the device pose distances (utils.distance, utils.py:5-31; utils.angular_distance, utils.py:34-69 -- what
+ * is_success and compute_reward call, reach.py:212-236): a6 / b6 are [count][6] float64 poses xyz + rpy (DEVICE pointers),
+ * out2[count][2] = {distance, angular distance}.  Lets the fixtures generated by the reference's own utils.py reach the
+ * device code directly (tests/test_gpu_parity.py). */
+int urgym_probe_pose_distance(void* handle, int count, const double* a6, const double* b6, double* out2, void* stream);
 
 /* Average device time (microseconds) of the step kernel over the calls since the last query, measured with
  * hipEvents on the launch stream; returns <0 if timing was not enabled. */

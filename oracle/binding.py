@@ -50,7 +50,10 @@ def lib():
         L.urgym_oracle_euler_from_quat.argtypes = [dp, dp]
         L.urgym_oracle_dyn_velocity.argtypes = [dp, dp, C.c_double, dp]
         L.urgym_oracle_closest.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, C.c_double, dp]
-        L.urgym_oracle_query.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int, dp, C.POINTER(C.c_int)]
+        L.urgym_oracle_query.argtypes = [dp, dp, C.c_int, C.c_double, C.c_int, C.c_int, dp, C.POINTER(C.c_int)]
+        L.urgym_oracle_integrate_obstacle.argtypes = [dp, dp, C.c_double]
+        L.urgym_oracle_set_primitive_margin.argtypes = [C.c_double]
+        L.urgym_oracle_last_epa_iterations.restype = C.c_int
         L.urgym_oracle_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, dp]
         L.urgym_oracle_hardware_threads.restype = C.c_int
         _lib = L
@@ -193,7 +196,7 @@ def closest(type_a, par_a, pose_a, type_b, par_b, pose_b, threshold=5.0):
     return dict(has_point=bool(out[0]), distance=out[1], penetrating=bool(out[2]), iterations=int(out[3]))
 
 
-def query(q, obst_pose=None, margin=0.01, gjk_start=0):
+def query(q, obst_pose=None, margin=0.01, gjk_start=0, scope=0):
     q = np.ascontiguousarray(q, dtype=np.float64)
     ld = np.zeros(5)
     coll = C.c_int(0)
@@ -203,8 +206,25 @@ def query(q, obst_pose=None, margin=0.01, gjk_start=0):
     else:
         op = np.ascontiguousarray(obst_pose, dtype=np.float64)
         has = 1
-    status = lib().urgym_oracle_query(_dp(q), _dp(op), has, margin, int(gjk_start), _dp(ld), C.byref(coll))
+    status = lib().urgym_oracle_query(_dp(q), _dp(op), has, margin, int(gjk_start), int(scope), _dp(ld), C.byref(coll))
     return ld, bool(coll.value), status
+
+
+def integrate_obstacle(pos_quat, vel6, dt=0.04):
+    """One env step (20 Bullet sub-steps) of the obstacle base; pos_quat = xyz + quaternion xyzw."""
+    pq = np.ascontiguousarray(pos_quat, dtype=np.float64).copy()
+    v = np.ascontiguousarray(vel6, dtype=np.float64)
+    lib().urgym_oracle_integrate_obstacle(_dp(pq), _dp(v), dt)
+    return pq
+
+
+def set_primitive_margin(m):
+    """What-if (tests only): collision margin of cylinders / boxes; < 0 restores Bullet's 0.001."""
+    lib().urgym_oracle_set_primitive_margin(float(m))
+
+
+def last_epa_iterations():
+    return lib().urgym_oracle_last_epa_iterations()
 
 
 def philox(seed, env, episode, attempt):

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <utility>
 #include <algorithm>
 
 #include "../include/urgym.h"
@@ -201,9 +202,15 @@ void forward_kinematics(const double q[6], X3 link[7]) {
 // ------------------------------------------------------------------------------------------------ shapes
 // [BULLET] collision shapes as pybullet builds them:
 //  HULL : btConvexHullShape of the STL vertices, core = the hull itself, margin = 0.001 (URDF default margin)
-//  CYLZ : btCylinderShapeZ(radius,radius,height/2): margin = min(0.04, 0.1*min half extent), core shrunk by it
-//  BOX  : btBoxShape(half): same safe-margin rule
-//  POINT: btSphereShape(r): core = centre point, margin = r
+//  CYLZ : btCylinderShapeZ(radius,radius,height/2) made by p.createCollisionShape (pyb_setup.py:748-752):
+//         PhysicsServerCommandProcessor ends createCollisionShape with shape->setMargin(m_defaultCollisionMargin = 0.001),
+//         and btCylinderShape::setMargin re-derives the implicit dimensions: core = (r - 0.001, h/2 - 0.001), margin 0.001.
+//         PINNED by the reference's own data: the link_dist slots of the observations stored in
+//         Trained_Models/*/best_model.zip (tests/golden/reference_observations.json) are reproduced to 1e-7 with
+//         0.001 and are off by up to 1.7e-3 with the constructor's "safe margin" (0.005), tests/test_reference_pins.py.
+//  BOX  : btBoxShape(half) through the same createCollisionShape: core = half - 0.001, margin 0.001 (pinned likewise
+//         by the table / track distances of the Sep-2023 checkpoints' observations).
+//  POINT: btSphereShape(r): core = centre point, margin = r (btSphereShape::getMargin returns the radius)
 enum ShapeType { SH_HULL = 0, SH_CYLZ = 1, SH_BOX = 2, SH_POINT = 3 };
 struct Shape {
   int type;
@@ -213,12 +220,11 @@ struct Shape {
   double margin;
   X3 pose;
 };
-const double CONVEX_DISTANCE_MARGIN = 0.04;  // [BULLET] btCollisionMargin.h
-inline double safe_margin(double hx, double hy, double hz) {
-  double mn = std::min(hx, std::min(hy, hz));
-  double sm = 0.1 * mn;
-  return sm < CONVEX_DISTANCE_MARGIN ? sm : CONVEX_DISTANCE_MARGIN;
-}
+const double PRIMITIVE_MARGIN = 0.001;  // [BULLET] PhysicsServerCommandProcessor::m_defaultCollisionMargin
+// What-if switch (tests only): >= 0 replaces the margin of cylinders / boxes, e.g. 0.005 = the "safe margin" of the
+// btCylinderShape constructor that round 1 assumed; tests/test_reference_pins.py shows that it misses the reference.
+double g_prim_margin_override = -1.0;
+inline double primitive_margin() { return g_prim_margin_override >= 0 ? g_prim_margin_override : PRIMITIVE_MARGIN; }
 Shape make_hull(int link /*1..6*/, const X3& pose) {
   Shape s{};
   s.type = SH_HULL;
@@ -231,7 +237,7 @@ Shape make_hull(int link /*1..6*/, const X3& pose) {
 Shape make_box(double hx, double hy, double hz, const X3& pose) {
   Shape s{};
   s.type = SH_BOX;
-  s.margin = safe_margin(hx, hy, hz);
+  s.margin = primitive_margin();
   s.hx = hx - s.margin;
   s.hy = hy - s.margin;
   s.hz = hz - s.margin;
@@ -241,7 +247,7 @@ Shape make_box(double hx, double hy, double hz, const X3& pose) {
 Shape make_cylinder_z(double radius, double height, const X3& pose) {
   Shape s{};
   s.type = SH_CYLZ;
-  s.margin = safe_margin(radius, radius, 0.5 * height);
+  s.margin = primitive_margin();
   s.hx = s.hy = radius - s.margin;
   s.hz = 0.5 * height - s.margin;
   s.pose = pose;
@@ -472,10 +478,116 @@ bool simplex_in(const Simplex& s, V3 w) {
   return false;
 }
 
+// ------------------------------------------------------------------------------------------------ penetration depth
+// [BULLET] When the core shapes overlap, btGjkPairDetector hands over to btGjkEpaPenetrationDepthSolver (btGjkEpa2's
+// expanding-polytope algorithm on the margin-inflated shapes) and p.getClosestPoints reports the NEGATIVE penetration
+// depth as the contact distance -- what pyb_setup.py:452 stores in link_dist and ReachObs.compute_reward
+// (reach.py:357-372) consumes on a terminal collision step.  Inflating both shapes by their margins adds
+// margin_A + margin_B to the support function of the Minkowski difference in every direction, so
+//     depth(inflated) = depth(cores) + margin_A + margin_B,   depth(cores) = min over unit n of h_{A-B}(n),
+// and the oracle computes depth(cores) with an expanding polytope of its own, converged to EPA_TOL.  Bullet's EPA stops
+// at EPA_ACCURACY = 1e-4 (btGjkEpa2.cpp) between its inner polytope and the support plane, i.e. its answer lies within
+// 1e-4 m BELOW the value computed here; that envelope is the parity bar for penetrating queries and cannot be
+// tightened without a pybullet to compare with [UNVERIFIED-BULLET].
+struct EpaResult {
+  double depth;    // >= 0: distance from the origin to the boundary of core_A - core_B
+  int iterations;
+  bool capped;
+};
+thread_local int g_last_epa_iterations = 0;  // probe for tests / sizing of the device workspace
+const double EPA_TOL = 1.0e-9;
+// The polytope lives in fixed slots exactly like the HIP path's LDS workspace (urgym_device.h epa_wave), so that both
+// sides pick the same faces, in the same order, with the same arithmetic: at most EPA_MAX_VERTS points, hence at most
+// 2 V - 4 = 156 <= EPA_MAX_FACES triangles.  Of 2456 random overlapping link <-> obstacle poses the median search took 16
+// expansions, 99 % at most 38, the longest 94; a search that reaches the cap returns its current (inner) value and is
+// flagged URGYM_STATUS_GJK_ITER.
+const int EPA_MAX_VERTS = 80, EPA_MAX_FACES = 192;
+
+// Works in B's frame like the device: X = pose of A in B's frame, w(n) = X S_A(X^T n) - S_B(-n).
+EpaResult epa_core_depth(const Shape& A, const Shape& B) {
+  X3 X;
+  X.R = mul(M3{{{B.pose.R.m[0][0], B.pose.R.m[1][0], B.pose.R.m[2][0]}, {B.pose.R.m[0][1], B.pose.R.m[1][1], B.pose.R.m[2][1]},
+               {B.pose.R.m[0][2], B.pose.R.m[1][2], B.pose.R.m[2][2]}}}, A.pose.R);
+  X.t = mulT(B.pose.R, A.pose.t - B.pose.t);
+  auto supp = [&](V3 n) { return (mul(X.R, support_local(A, mulT(X.R, n))) + X.t) - support_local(B, -n); };
+  struct Face { int i, j, k; V3 n; double d; bool alive, degenerate; };
+  V3 pts[EPA_MAX_VERTS];
+  Face faces[EPA_MAX_FACES];
+  for (auto& f : faces) f = Face{0, 0, 0, v3(0, 0, 0), 0.0, false, false};
+  int nv = 0;
+  auto make_face = [&](int i, int j, int k, V3 pi, V3 pj, V3 pk) {
+    Face f{i, j, k, v3(0, 0, 0), 1e300, true, true};
+    V3 n = cross(pj - pi, pk - pi);
+    double l2 = len2(n);
+    if (l2 > 1e-40) {
+      f.n = n * (1.0 / std::sqrt(l2));
+      f.d = dot(f.n, pi);
+      f.degenerate = false;
+    }
+    return f;
+  };
+  // initial tetrahedron: support points of the four tetrahedral directions (it need not contain the origin yet: faces that
+  // have the origin outside carry d < 0 and are expanded first)
+  const double t = 0.5773502691896258;
+  const V3 dirs[4] = {v3(t, t, t), v3(t, -t, -t), v3(-t, t, -t), v3(-t, -t, t)};
+  for (int i = 0; i < 4; i++) pts[nv++] = supp(dirs[i]);
+  const int tet[4][4] = {{0, 1, 2, 3}, {0, 3, 1, 2}, {0, 2, 3, 1}, {1, 3, 2, 0}};
+  for (int f = 0; f < 4; f++) {
+    int i = tet[f][0], j = tet[f][1], k = tet[f][2], o = tet[f][3];
+    V3 n = cross(pts[j] - pts[i], pts[k] - pts[i]);
+    if (dot(n, pts[o] - pts[i]) > 0) std::swap(j, k);  // outward
+    faces[f] = make_face(i, j, k, pts[i], pts[j], pts[k]);
+  }
+  EpaResult res{0.0, 0, false};
+  for (;;) {
+    int best = -1;
+    for (int f = 0; f < EPA_MAX_FACES; f++)
+      if (faces[f].alive && (best < 0 || faces[f].d < faces[best].d)) best = f;  // ties: the lowest slot
+    const Face bf = faces[best];
+    const V3 w = supp(bf.n);
+    const double gain = dot(bf.n, w) - bf.d;
+    if (gain <= EPA_TOL || nv >= EPA_MAX_VERTS) {
+      res.capped = gain > EPA_TOL;
+      res.depth = bf.d > 0 ? bf.d : 0.0;  // d < 0: the origin is on (or a hair outside) the boundary -> cores just touch
+      g_last_epa_iterations = res.iterations;
+      return res;
+    }
+    res.iterations++;
+    // faces that see w die; their directed edges are the rim candidates (ascending slot, edge order ij, jk, ki)
+    int cand[3 * EPA_MAX_FACES], nc = 0;
+    for (int f = 0; f < EPA_MAX_FACES; f++) {
+      Face& F = faces[f];
+      if (!F.alive) continue;
+      if (F.degenerate || dot(F.n, w) - F.d > 1e-14) {
+        F.alive = false;
+        cand[nc++] = (F.i << 8) | F.j; cand[nc++] = (F.j << 8) | F.k; cand[nc++] = (F.k << 8) | F.i;
+      }
+    }
+    // horizon = candidates whose reverse is not a candidate; new faces fill the free slots in ascending order
+    int slot = 0;
+    for (int c = 0; c < nc; c++) {
+      const int rev = ((cand[c] & 255) << 8) | (cand[c] >> 8);
+      bool found = false;
+      for (int x = 0; x < nc; x++) found = found || cand[x] == rev;
+      if (found) continue;
+      while (slot < EPA_MAX_FACES && faces[slot].alive) slot++;
+      if (slot >= EPA_MAX_FACES) {  // cannot happen while 2 V - 4 <= EPA_MAX_FACES; mirrors the device's exit
+        res.capped = true;
+        res.depth = bf.d > 0 ? bf.d : 0.0;
+        g_last_epa_iterations = res.iterations;
+        return res;
+      }
+      const int a = cand[c] >> 8, b = cand[c] & 255;
+      faces[slot] = make_face(a, b, nv, pts[a], pts[b], w);
+    }
+    pts[nv++] = w;
+  }
+}
+
 struct GjkResult {
   bool has_point;     // a closest point within max_dist was produced (pybullet getClosestPoints returns a non-empty list)
   double distance;    // signed distance between the margin-inflated shapes
-  bool penetrating;   // cores overlap: Bullet would run EPA here; the oracle clamps (see DESIGN.md "deviations")
+  bool penetrating;   // cores overlap: the distance is -(penetration depth), see epa_core_depth
   int iterations;
 };
 
@@ -563,14 +675,18 @@ GjkResult gjk_distance(const Shape& A, const Shape& B, double threshold, const V
       valid = true;
     }
   }
-  // Bullet enters its penetration-depth (EPA) solver when the core shapes touch/overlap.  Not restated yet:
-  // the oracle reports the clamped value -(marginA+marginB) and flags it.
+  // Bullet enters its penetration-depth solver when the core shapes touch/overlap (checkPenetration && !isValid), and
+  // also -- catchDegeneratePenetrationCase -- whenever the core distance is below gGjkEpaPenetrationTolerance = 0.001;
+  // in that second case EPA's answer replaces GJK's only when it is deeper, and the two agree within EPA_ACCURACY, so
+  // GJK's value stands here.
   if (!valid || degenerate == 5 || degenerate == 6 || degenerate == 13 || (degenerate == 3)) {
     double l2 = len2(v);
     if (!valid || l2 < REL_ERROR2) {
+      EpaResult e = epa_core_depth(a, b);
       res.penetrating = true;
       res.has_point = true;
-      res.distance = -margin;
+      res.distance = -(e.depth + margin);
+      if (e.capped) res.iterations = 1001;  // reported as URGYM_STATUS_GJK_ITER
       return res;
     }
   }
@@ -610,14 +726,27 @@ V3 capsule_mid(int l, const X3& pose) {
   return mul(pose.R, v3(0.5 * (c[0] + c[3]), 0.5 * (c[1] + c[4]), 0.5 * (c[2] + c[5]))) + pose.t;
 }
 
-// PyBullet.get_link_distances (pyb_setup.py:439-456): links 2..6 vs obstacle, distance=5.0
-void link_distances(const X3 link[7], const Shape& obstacle, double out[5], int* status, int gjk_start) {
+// PyBullet.get_link_distances (pyb_setup.py:439-456): links 2..6 vs obstacle, distance=5.0.
+// scope == URGYM_LINK_DIST_WORKBENCH: per link the minimum over obstacle, table, track (include/urgym.h) -- the rule that
+// reproduces the observations stored with the Sep-2023 Obs / Sta checkpoints (tests/test_reference_pins.py).
+void link_distances(const X3 link[7], const Shape& obstacle, double out[5], int* status, int gjk_start, int scope) {
+  const bool guided = gjk_start == URGYM_GJK_START_GUIDED;
   for (int i = 0; i < 5; i++) {
     V3 ax = guided_axis(i + 2, link[i + 2], obstacle.pose.t);
-    GjkResult r = gjk_distance(make_hull(i + 2, link[i + 2]), obstacle, 5.0, gjk_start == URGYM_GJK_START_GUIDED ? &ax : nullptr);
+    GjkResult r = gjk_distance(make_hull(i + 2, link[i + 2]), obstacle, 5.0, guided ? &ax : nullptr);
     out[i] = r.distance;
     if (r.penetrating) *status |= URGYM_STATUS_PENETRATION;
     if (r.iterations > 1000) *status |= URGYM_STATUS_GJK_ITER;
+    if (scope == URGYM_LINK_DIST_WORKBENCH) {
+      Shape objs[2] = {scene_table(), scene_track()};
+      for (int o = 0; o < 2; o++) {
+        ax = guided_axis(i + 2, link[i + 2], objs[o].pose.t);
+        GjkResult rb = gjk_distance(make_hull(i + 2, link[i + 2]), objs[o], 5.0, guided ? &ax : nullptr);
+        if (rb.distance < out[i]) out[i] = rb.distance;
+        if (rb.penetrating) *status |= URGYM_STATUS_PENETRATION;
+        if (rb.iterations > 1000) *status |= URGYM_STATUS_GJK_ITER;
+      }
+    }
   }
 }
 // PyBullet.check_collision (pyb_setup.py:382-429). has_obstacle mirrors `keys[5] == 'obstacle'` (398-399).
@@ -691,6 +820,9 @@ inline void sample_euler_obstacle(double u_sign, double u_roll, double u_pitch, 
 }
 
 // ------------------------------------------------------------------------------------------------ env
+// ur5e.urdf:237,245,253,261,269,277: lower = -upper
+const double UR5E_JOINT_LIMIT[6] = {2 * M_PI, 2 * M_PI, M_PI, 2 * M_PI, 2 * M_PI, 2 * M_PI};
+
 struct Oracle {
   urgym_config cfg;
   urgym_buffers buf;
@@ -721,14 +853,36 @@ void dyn_velocity(const double start[6], const double end[6], double T, double v
   axis_angle_bullet(dq, &axis, &angle);
   vel[3] = axis.x * angle / T; vel[4] = axis.y * angle / T; vel[5] = axis.z * angle / T;
 }
-// [BULLET] PyBullet.step (pyb_setup.py:52-55): 20 x stepSimulation at 1/500 s.  For the mass-0 obstacle this is
-// btMultiBody::stepPositionsMultiDof: p += v dt; R <- exp([w] dt) R (world-frame omega), normalised each sub-step.
+// [BULLET] PyBullet.step (pyb_setup.py:52-55): 20 x stepSimulation at 1/500 s.  For the mass-0 (fixed-base btMultiBody)
+// obstacle each sub-step is
+//   (a) btMultiBody::computeAccelerationsArticulatedBodyAlgorithmMultiDof: the base's spatial acceleration is zero, but
+//       its world-frame read-out vdot = R^T (a_lin + w_local x v_local) keeps the transport term, and
+//       applyDeltaVeeMultiDof adds h * (w x v) to the base's LINEAR velocity (w itself is unchanged);
+//   (b) btMultiBody::stepPositionsMultiDof: p += h v; R <- exp([w] h) R (world-frame omega), normalised.
+// resetBaseVelocity (reach.py:745 -> pyb_setup.py:340-349) restores the task's (v, w) before every env step, so the
+// drift of v restarts from the task's value each time.  PINNED by the reference's own data: the two consecutive
+// UR5DynReach-v1 observations stored in Trained_Models/Trained_Dyn/best_model.zip are reproduced to 3e-8 by this rule
+// and are off by 5e-4 m without (a) (tests/test_reference_pins.py).
+// Displacement of the obstacle base over one env step for the twist (v, w) that set_velocity re-applies every step: a
+// constant per episode, kept in rows 6..8 of the obst_vel state so that the HIP step adds it instead of looping.
+void step_displacement(const double vel[6], int substeps, double h, double dp[3]) {
+  V3 v = v3(vel[0], vel[1], vel[2]);
+  const V3 w = v3(vel[3], vel[4], vel[5]);
+  double p[3] = {0, 0, 0};
+  for (int k = 0; k < substeps; k++) {
+    v = v + cross(w, v) * h;
+    p[0] += h * v.x; p[1] += h * v.y; p[2] += h * v.z;
+  }
+  dp[0] = p[0]; dp[1] = p[1]; dp[2] = p[2];
+}
 void integrate_obstacle(const urgym_buffers& b, int n, int N, const double vel[6], int substeps, double h) {
   double p[3] = {S(b.obst_pos, 0, n, N), S(b.obst_pos, 1, n, N), S(b.obst_pos, 2, n, N)};
   Quat q{S(b.obst_quat, 0, n, N), S(b.obst_quat, 1, n, N), S(b.obst_quat, 2, n, N), S(b.obst_quat, 3, n, N)};
+  V3 v = v3(vel[0], vel[1], vel[2]);
+  const V3 w = v3(vel[3], vel[4], vel[5]);
   for (int k = 0; k < substeps; k++) {
-    for (int i = 0; i < 3; i++) p[i] += h * vel[i];
-    V3 w = v3(vel[3], vel[4], vel[5]);
+    v = v + cross(w, v) * h;
+    p[0] += h * v.x; p[1] += h * v.y; p[2] += h * v.z;
     double ang = std::sqrt(len2(w));
     if (ang * h > 0.5 * (M_PI * 0.5)) ang = 0.5 * (M_PI * 0.5) / h;  // ANGULAR_MOTION_THRESHOLD
     V3 ax;
@@ -741,6 +895,15 @@ void integrate_obstacle(const urgym_buffers& b, int n, int N, const double vel[6
   }
   for (int i = 0; i < 3; i++) S(b.obst_pos, i, n, N) = p[i];
   S(b.obst_quat, 0, n, N) = q.x; S(b.obst_quat, 1, n, N) = q.y; S(b.obst_quat, 2, n, N) = q.z; S(b.obst_quat, 3, n, N) = q.w;
+}
+
+// obst_vel state rows: 0..5 the episode's twist (v, w), 6..8 its displacement per env step (include/urgym.h)
+void store_velocity(const urgym_config& c, const urgym_buffers& b, int n, const double vel[6]) {
+  const int N = c.num_envs;
+  double dp[3];
+  step_displacement(vel, 20, c.dt / 20.0, dp);
+  for (int i = 0; i < 6; i++) S(b.obst_vel, i, n, N) = vel[i];
+  for (int i = 0; i < 3; i++) S(b.obst_vel, 6 + i, n, N) = dp[i];
 }
 
 struct Pose6 {
@@ -857,11 +1020,11 @@ void reset_env(Oracle& o, int n) {
     set_obstacle_pose(b, n, N, start);  // reach.py:319 / 678
     double vel[6] = {0, 0, 0, 0, 0, 0};
     if (c.env_kind == URGYM_ENV_DYN) dyn_velocity(start, end, c.dyn_time_duration, vel);
-    for (int i = 0; i < 6; i++) S(b.obst_vel, i, n, N) = vel[i];
+    store_velocity(c, b, n, vel);
     Shape obst = scene_obstacle(obstacle_pose(b, n, N));
     if (c.check_collision) coll = check_collision(link, true, &obst, c.collision_margin, c.gjk_start);  // reach.py:323 / 679
     double ld[5];
-    link_distances(link, obst, ld, &status, c.gjk_start);  // reach.py:324-325 / 680-681
+    link_distances(link, obst, ld, &status, c.gjk_start, c.link_dist_scope);  // reach.py:324-325 / 680-681
     for (int i = 0; i < 5; i++) S(b.link_dist, i, n, N) = ld[i];
     if (coll) status |= URGYM_STATUS_RESET_COLLISION;
   }
@@ -903,11 +1066,11 @@ void refresh_env(Oracle& o, int n) {
     set_obstacle_pose(b, n, N, start);
     double vel[6] = {0, 0, 0, 0, 0, 0};
     if (c.env_kind == URGYM_ENV_DYN) dyn_velocity(start, end, c.dyn_time_duration, vel);
-    for (int i = 0; i < 6; i++) S(b.obst_vel, i, n, N) = vel[i];
+    store_velocity(c, b, n, vel);
     Shape obst = scene_obstacle(obstacle_pose(b, n, N));
     bool coll = c.check_collision ? check_collision(link, true, &obst, c.collision_margin, c.gjk_start) : false;
     double ld[5];
-    link_distances(link, obst, ld, &status, c.gjk_start);
+    link_distances(link, obst, ld, &status, c.gjk_start, c.link_dist_scope);
     for (int i = 0; i < 5; i++) S(b.link_dist, i, n, N) = ld[i];
     b.collision[n] = coll ? 1 : 0;
   }
@@ -938,6 +1101,9 @@ void step_env(Oracle& o, int n, const float* action) {
     volatile float t2 = t1 * 0.1f;
     q[i] = S(b.q, i, n, N) + (double)t2;
     S(b.q, i, n, N) = q[i];
+    // resetJointState does not clamp (pyb_setup.py:338); past the URDF limit (ur5e.urdf:237-277) Bullet's limit
+    // constraint would act during stepSimulation, which this restatement does not model: flagged, not altered
+    if (std::fabs(q[i]) > UR5E_JOINT_LIMIT[i]) status |= URGYM_STATUS_JOINT_LIMIT;
   }
   // 2. ReachDyn.set_velocity (core.py:305-306; reach.py:728-753)
   double vel_obs[6] = {0, 0, 0, 0, 0, 0};
@@ -993,7 +1159,7 @@ void step_env(Oracle& o, int n, const float* action) {
   } else if (c.env_kind == URGYM_ENV_OBS) {
     // ReachObs.compute_reward (reach.py:356-374)
     double ld[5];
-    link_distances(link, obst, ld, &status, c.gjk_start);
+    link_distances(link, obst, ld, &status, c.gjk_start, c.link_dist_scope);
     reward += succ ? c.w_success : 0.0;
     reward += coll ? c.w_collision : 0.0;
     reward += c.w_distance * d;
@@ -1014,7 +1180,7 @@ void step_env(Oracle& o, int n, const float* action) {
       reward += c.w_distance * d;
       reward += c.w_orientation * th;
       double ld[5];
-      link_distances(link, obst, ld, &status, c.gjk_start);
+      link_distances(link, obst, ld, &status, c.gjk_start, c.link_dist_scope);
       double sum = 0.0;
       for (int i = 0; i < 5; i++) {
         double change = ld[i] - S(b.link_dist, i, n, N);
@@ -1063,6 +1229,7 @@ int urgym_oracle_config_default(int env_kind, int num_envs, urgym_config* c) {
   c->check_collision = 1;
   c->max_reset_tries = 4096;
   c->gjk_start = URGYM_GJK_START_BULLET;
+  c->link_dist_scope = URGYM_LINK_DIST_OBSTACLE;
   c->dyn_motion_steps = 25;
   c->action_scale = M_PI * 0.1;
   c->dt = 20.0 / 500.0;
@@ -1186,6 +1353,16 @@ void urgym_oracle_quat_from_euler(const double* rpy, double* q) {
 }
 void urgym_oracle_euler_from_quat(const double* q, double* rpy) { euler_from_quat_bullet(Quat{q[0], q[1], q[2], q[3]}, rpy); }
 void urgym_oracle_dyn_velocity(const double* start, const double* end, double T, double* vel) { dyn_velocity(start, end, T, vel); }
+// one env step (20 sub-steps of h = dt/20) of the obstacle base: pos_quat = xyz + quaternion xyzw, updated in place
+void urgym_oracle_integrate_obstacle(double* pos_quat, const double* vel6, double dt) {
+  double pos[3] = {pos_quat[0], pos_quat[1], pos_quat[2]}, quat[4] = {pos_quat[3], pos_quat[4], pos_quat[5], pos_quat[6]};
+  urgym_buffers b{};
+  b.obst_pos = pos;
+  b.obst_quat = quat;
+  integrate_obstacle(b, 0, 1, vel6, 20, dt / 20.0);
+  for (int i = 0; i < 3; i++) pos_quat[i] = pos[i];
+  for (int i = 0; i < 4; i++) pos_quat[3 + i] = quat[i];
+}
 
 static Shape probe_shape(int type, const double* params, const double* pose_xyz_quat) {
   Quat q{pose_xyz_quat[3], pose_xyz_quat[4], pose_xyz_quat[5], pose_xyz_quat[6]};
@@ -1206,7 +1383,7 @@ int urgym_oracle_closest(int type_a, const double* par_a, const double* pose_a, 
   return URGYM_OK;
 }
 // link distances + collision for a joint vector and an obstacle pose (xyz+quat); has_obstacle=0 -> Ori rules
-int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacle, double margin, int gjk_start, double* ld5, int* collision) {
+int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacle, double margin, int gjk_start, int scope, double* ld5, int* collision) {
   X3 link[7];
   forward_kinematics(q, link);
   int status = 0;
@@ -1214,12 +1391,14 @@ int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacl
   if (has_obstacle) {
     Quat qq{obst_pose[3], obst_pose[4], obst_pose[5], obst_pose[6]};
     obst = scene_obstacle(X3{quat_to_mat(qq), v3(obst_pose[0], obst_pose[1], obst_pose[2])});
-    link_distances(link, obst, ld5, &status, gjk_start);
+    link_distances(link, obst, ld5, &status, gjk_start, scope);
   }
   *collision = check_collision(link, has_obstacle != 0, has_obstacle ? &obst : nullptr, margin, gjk_start) ? 1 : 0;
   return status;
 }
 void urgym_oracle_set_emulation(int flags) { g_emulate = flags; }
+int urgym_oracle_last_epa_iterations(void) { return g_last_epa_iterations; }
+void urgym_oracle_set_primitive_margin(double m) { g_prim_margin_override = m; }
 void urgym_oracle_philox(uint64_t seed, uint32_t env, uint32_t episode, uint32_t attempt, double* u20) {
   Draws d = draw_attempt(seed, env, episode, attempt);
   std::memcpy(u20, d.u, sizeof(d.u));

@@ -15,10 +15,10 @@ static X3 pose_to_x3(const double* p) {
 static ShapeDesc desc(int type, const double* par, double* margin) {
   ShapeDesc s;
   s.type = type; s.hull = 0; s.hx = s.hy = s.hz = 0;
-  auto safe = [](double a, double b, double c) { double m = fmin(a, fmin(b, c)) * 0.1; return m < 0.04 ? m : 0.04; };
+  const double m = 0.001;  // Bullet's default collision margin on every createCollisionShape primitive (urgym_hip.hip M_PRIM)
   if (type == SH_HULL) { s.hull = (int)par[0] - 1; *margin = 0.001; }
-  else if (type == SH_CYLZ) { double m = safe(par[0], par[0], 0.5 * par[1]); s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; *margin = m; }
-  else if (type == SH_BOX) { double m = safe(par[0], par[1], par[2]); s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; *margin = m; }
+  else if (type == SH_CYLZ) { s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; *margin = m; }
+  else if (type == SH_BOX) { s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; *margin = m; }
   else { *margin = par[0]; }
   return s;
 }

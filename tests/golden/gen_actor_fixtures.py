@@ -5,8 +5,10 @@
 
 Source: Trained_Models/Trained_{Ori,Obs,Sta,Dyn}/best_model.zip -> policy.pth, loaded with torch.load(weights_only=True)
 (nothing from the file is executed).  These are DATA files of the reference (SB3 MultiInputPolicy weights); the GPU box
-has no /root/reference, so the closed-loop tests read these fixtures instead.  Also records the aggregate closed-loop
-results the reference ships next to each checkpoint (best.txt / best_modeltest_result.txt, first two lines).
+has no /root/reference, so the closed-loop tests read these fixtures instead.  Also records the closed-loop results the
+reference ships next to each checkpoint (best.txt / best_modeltest_result.txt): the two aggregate lines and statistics of the
+per-trial rows "reward, success, last step" (model_test.py:59-60) -- early failures (an unsuccessful trial that ended before
+step 99 = a collision), time-outs, percentiles of the last step and mean reward of the successful trials.
 """
 import argparse
 import io
@@ -38,8 +40,16 @@ def main():
         reward = float(re.search(r"(-?[\d.]+)\s*$", lines[1]).group(1))
         rows = [l.split(",") for l in lines[2:] if l.strip()]
         steps = np.array([float(r[2]) for r in rows])
+        rew = np.array([float(r[0]) for r in rows])
+        ok = np.array([float(r[1]) for r in rows]) > 0.5
         summary[name.lower()] = {"success_rate_percent": rate, "mean_episode_reward": reward, "trials": len(rows),
-                                 "mean_last_step_index": float(steps.mean()), "in_features": int(arrs["latent_pi_0_weight"].shape[1])}
+                                 "mean_last_step_index": float(steps.mean()), "in_features": int(arrs["latent_pi_0_weight"].shape[1]),
+                                 "early_fail_percent": 100.0 * float((~ok & (steps < 99)).mean()),
+                                 "timeout_percent": 100.0 * float((steps >= 99).mean()),
+                                 "success_last_step_p5": float(np.percentile(steps[ok], 5)),
+                                 "success_last_step_p50": float(np.percentile(steps[ok], 50)),
+                                 "success_last_step_p95": float(np.percentile(steps[ok], 95)),
+                                 "mean_success_reward": float(rew[ok].mean()), "mean_failure_reward": float(rew[~ok].mean())}
         print(name, {k: v.shape for k, v in arrs.items()}, summary[name.lower()])
     with open(os.path.join(out_dir, "reference_results.json"), "w") as f:
         json.dump(summary, f, indent=1)

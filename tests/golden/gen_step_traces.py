@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Generate tests/golden/step_trace_{ori,obs,dyn,sta}.npz with the CPU oracle (seeded), as regression vectors for the
-HIP path.  These are outputs of the build's own oracle, not of the reference (which cannot run here: no pybullet):
+"""Generate tests/golden/step_trace_{ori,obs,dyn,sta,obs_wb,sta_wb}.npz with the CPU oracle (seeded), as regression vectors
+for the HIP path (*_wb: link_dist_scope = URGYM_LINK_DIST_WORKBENCH, the rule of the reference's Sep-2023 checkpoints).
+These are outputs of the build's own oracle, not of the reference (which cannot run here: no pybullet; what the reference
+itself pins is in tests/golden/reference_observations.json):
 
     python tests/golden/gen_step_traces.py
 
@@ -21,15 +23,16 @@ STATE = ("q", "goal", "obst_start", "obst_end", "obst_pos", "obst_quat", "obst_v
 
 
 def main():
-    for name, kind in (("ori", _abi.ENV_ORI), ("obs", _abi.ENV_OBS), ("dyn", _abi.ENV_DYN), ("sta", _abi.ENV_STA)):
-        env = ob.OracleEnv(kind, N, threads=4)
+    for name, kind, scope in (("ori", _abi.ENV_ORI, 0), ("obs", _abi.ENV_OBS, 0), ("dyn", _abi.ENV_DYN, 0), ("sta", _abi.ENV_STA, 0),
+                              ("obs_wb", _abi.ENV_OBS, 1), ("sta_wb", _abi.ENV_STA, 1)):
+        env = ob.OracleEnv(kind, N, threads=4, link_dist_scope=scope)
         env.reset(seed=SEED)
         if kind == _abi.ENV_STA:  # make a third of the obstacles move (the 18-column form of set_goal_and_obstacle, reach.py:492-503)
             mv = np.arange(0, N, 3)
             env.buf["obst_end"][:, mv] = env.buf["obst_start"][:, mv] + np.array([[0.15], [0.25], [0.1], [0.4], [-0.3], [0.0]])
             env.refresh()
         rng = np.random.default_rng(SEED + kind)
-        out = {"seed": SEED, "kind": kind}
+        out = {"seed": SEED, "kind": kind, "link_dist_scope": scope}
         for k in STATE:
             out["reset_" + k] = env.buf[k].copy()
         out["reset_observation"] = env.buf["observation"].copy()

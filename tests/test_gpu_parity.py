@@ -4,7 +4,8 @@ BASELINE.json's full size — through size-independent properties.
 
 Tolerances (written here, north_star: "within 1e-4 abs"):
   observation / achieved / desired   1e-4 abs  (measured: <= 1e-6; Euler angles compared modulo 2*pi: atan2 branch cut)
-  link distances (state)             1e-8 abs  — EXCEPT at ill-conditioned queries (about 6 in 1e4): there the reference
+  link distances (state)             1e-8 abs  — incl. penetration depths (negative; EPA on both sides, same polytope
+                                     slot by slot) — EXCEPT at ill-conditioned queries (about 6 in 1e4): there the reference
                                      algorithm itself (Bullet GJK, sliver-tetrahedron exit) is discontinuous and the
                                      ORACLE's own answer jumps between 2-3 values ~1e-6..1e-5 apart under a 1e-14
                                      perturbation of the pose.  At such a query the HIP value must lie inside the range
@@ -47,7 +48,7 @@ def obs_diff(kind, a, b):
     return float(d.max()) if d.size else 0.0
 
 
-def link_dist_slack(oracle, gpu_ld, ref_ld, q, obst_pos, obst_quat, gjk_start=0):
+def link_dist_slack(oracle, gpu_ld, ref_ld, q, obst_pos, obst_quat, gjk_start=0, scope=0):
     """Per-env allowance for |gpu - oracle| link distances [5, N]: zero where they agree to LD_TOL; where they do not,
     the query must be one at which the oracle itself is unstable — re-run the oracle under 1e-14 pose perturbations and
     require the HIP value inside the range of its answers.  Returns the measured |difference| (0 where within LD_TOL)."""
@@ -58,7 +59,7 @@ def link_dist_slack(oracle, gpu_ld, ref_ld, q, obst_pos, obst_quat, gjk_start=0)
         vals = []
         for _ in range(200):
             pose = np.r_[obst_pos[:, n] + rng.normal(0, 1e-14, 3), obst_quat[:, n]]
-            vals.append(oracle.query(q[:, n], pose, gjk_start=gjk_start)[0][i])
+            vals.append(oracle.query(q[:, n], pose, gjk_start=gjk_start, scope=scope)[0][i])
         lo, hi = min(vals), max(vals)
         assert hi - lo >= 0.9 * diff[i, n], f"link {i + 2} env {n}: differs by {diff[i, n]:.3e} at a WELL-conditioned query (oracle spread {hi - lo:.3e})"
         assert lo - 1e-8 <= gpu_ld[i, n] <= hi + 1e-8, f"link {i + 2} env {n}: {gpu_ld[i, n]} outside the oracle's range [{lo}, {hi}]"
@@ -90,7 +91,7 @@ def step_both(oracle, kind, env, orc, a, where=""):
         assert np.abs(st["obst_pos"] - orc.buf["obst_pos"]).max() < 1e-12, where
         assert np.abs(st["obst_quat"] - orc.buf["obst_quat"]).max() < 1e-12, where
         slack = link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"],
-                                gjk_start=orc.cfg.gjk_start)
+                                gjk_start=orc.cfg.gjk_start, scope=orc.cfg.link_dist_scope)
         n_unstable = int((slack > 0).sum())
         reward_slack = float(max(orc.cfg.w_link)) * slack.sum(0)
         env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())
@@ -217,12 +218,15 @@ def test_guided_start_deviation_from_bullet_start():
         e.close()
 
 
-@pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2], ("sta",) + KINDS[3]])
+@pytest.mark.parametrize("name,env_id,kind", [("ori",) + KINDS[0], ("obs",) + KINDS[1], ("dyn",) + KINDS[2], ("sta",) + KINDS[3],
+                                              ("obs_wb",) + KINDS[1], ("sta_wb",) + KINDS[3]])
 def test_golden_traces(oracle, name, env_id, kind):
-    """Committed vectors (tests/golden/step_trace_*.npz, produced by the oracle with gen_step_traces.py)."""
+    """Committed vectors (tests/golden/step_trace_*.npz, produced by the oracle with gen_step_traces.py); *_wb: the
+    URGYM_LINK_DIST_WORKBENCH scope of the reference's Sep-2023 checkpoints."""
     g = np.load(os.path.join(HERE, "golden", f"step_trace_{name}.npz"))
     n = g["actions"].shape[1]
-    env = make_vec(env_id, num_envs=n, seed=int(g["seed"]))
+    scope = int(g["link_dist_scope"])
+    env = make_vec(env_id, num_envs=n, seed=int(g["seed"]), link_dist_scope=scope)
     env.reset(seed=int(g["seed"]))
     if kind == _abi.ENV_STA:  # the generator made every third obstacle a moving one (gen_step_traces.py)
         mv = np.arange(0, n, 3)
@@ -235,7 +239,7 @@ def test_golden_traces(oracle, name, env_id, kind):
         if k != "link_dist":
             assert np.abs(st[k].astype(np.float64) - g["reset_" + k]).max() <= 1e-12, k
     if kind != _abi.ENV_ORI:
-        link_dist_slack(oracle, st["link_dist"], g["reset_link_dist"], g["reset_q"], g["reset_obst_pos"], g["reset_obst_quat"])
+        link_dist_slack(oracle, st["link_dist"], g["reset_link_dist"], g["reset_q"], g["reset_obst_pos"], g["reset_obst_quat"], scope=scope)
     assert obs_diff(kind, np_(env.buf["observation"]), g["reset_observation"]) < OBS_TOL
     w_max = {_abi.ENV_ORI: 0.0, _abi.ENV_OBS: 100.0, _abi.ENV_DYN: 8 / 13 * 50, _abi.ENV_STA: 8 / 13 * 50}[kind]
     for t in range(g["actions"].shape[0]):
@@ -246,7 +250,7 @@ def test_golden_traces(oracle, name, env_id, kind):
         reward_slack = None
         if kind != _abi.ENV_ORI:
             ld = np_(env.buf["link_dist"])
-            slack = link_dist_slack(oracle, ld, g["step_link_dist"][t], g["step_q"][t], g["step_obst_pos"][t], g["step_obst_quat"][t])
+            slack = link_dist_slack(oracle, ld, g["step_link_dist"][t], g["step_q"][t], g["step_obst_pos"][t], g["step_obst_quat"][t], scope=scope)
             reward_slack = w_max * slack.sum(0)
             env.buf["link_dist"].copy_(torch.from_numpy(g["step_link_dist"][t]).cuda())
         assert_outputs_match(kind, env, ref, where=f"golden step {t}", reward_slack=reward_slack)
@@ -361,15 +365,26 @@ def test_device_closest_distance_primitives(oracle):
         elif kind == 3: cases.append((H, [int(rng.integers(1, 4)), 0, 0], pa, H, [int(rng.integers(3, 7)), 0, 0], pb, 5.0))
         elif kind == 4: cases.append((B_, [0.025, 0.025, 0.025], pa, C_, [0.05, 0.4, 0], pb, 5.0))
         else: cases.append((S_, [0.02, 0, 0], pa, C_, [0.05, 0.4, 0], pb, 5.0))
+    for i in range(400):  # overlapping pairs: the other shape sits a few cm from the link's origin -> penetration depths
+        pa = np.r_[rng.uniform(-0.5, 0.5, 3) + [0.5, 0, 0.35], Rot.random(random_state=int(rng.integers(1 << 30))).as_quat()]
+        pb = np.r_[pa[:3] + rng.normal(0, 0.04, 3), Rot.random(random_state=int(rng.integers(1 << 30))).as_quat()]
+        kind = i % 4
+        if kind == 0: cases.append((H, [int(rng.integers(2, 7)), 0, 0], pa, C_, [0.05, 0.4, 0], pb, 5.0))
+        elif kind == 1: cases.append((H, [int(rng.integers(2, 7)), 0, 0], pa, B_, [0.1, 0.55, 0.06], pb, 5.0))
+        elif kind == 2: cases.append((H, [int(rng.integers(1, 4)), 0, 0], pa, H, [int(rng.integers(3, 7)), 0, 0], pb, 5.0))
+        else: cases.append((B_, [0.025, 0.025, 0.025], pa, C_, [0.05, 0.4, 0], pb, 5.0))
     for thr in (5.0, 0.01):
         sel = [c for c in cases if c[6] == thr]
         d, info = env.probe_closest([c[0] for c in sel], [c[1] for c in sel], [c[2] for c in sel], [c[3] for c in sel],
                                     [c[4] for c in sel], [c[5] for c in sel], threshold=thr)
-        bad = 0
+        bad, n_pen = 0, 0
         for k, c in enumerate(sel):
             ref = oracle.closest(c[0], c[1], c[2], c[3], c[4], c[5], threshold=thr)
             if ref["penetrating"]:
-                assert info[k] & 1, (k, ref)       # both sides see overlapping cores
+                assert info[k] & 1, (k, ref)       # both sides see overlapping cores ...
+                n_pen += 1
+                if thr > 1.0:                      # ... and report the same penetration depth (EPA on both sides)
+                    assert d[k] < 0 and abs(d[k] - ref["distance"]) < 1e-8, (k, c, d[k], ref)
                 continue
             if thr < 1.0:                           # boolean query: agree on "closer than the threshold"
                 hit = (not (info[k] & 4)) and d[k] <= thr
@@ -380,6 +395,7 @@ def test_device_closest_distance_primitives(oracle):
                 bad += 1                            # ill-conditioned query (module docstring): must stay rare and small
                 assert abs(d[k] - ref["distance"]) < 1e-4
         assert bad <= max(3, len(sel) // 200)
+        assert thr < 1.0 or n_pen > 20  # the overlapping pairs were really exercised
     env.close()
 
 
@@ -585,3 +601,174 @@ def test_prefetched_reset_is_bitwise_the_reset_kernel_at_scale(monkeypatch):
             assert torch.equal(x, y) or torch.equal(torch.nan_to_num(x.double()), torch.nan_to_num(y.double())), (k, t)
     for e in envs:
         e.close()
+
+
+# ------------------------------------------------------------------------------------------------ round-2 additions
+def test_pose_distances_against_reference_utils_fixtures():
+    """tests/golden/utils_golden.json was produced by the reference's OWN UR_gym/utils.py (gen_utils_golden.py): every pair of
+    it, incl. the theta -> 0 and theta -> pi edge cases and the float32-rounded poses, goes through the DEVICE functions that
+    is_success / compute_reward call in P4 (urgym_probe_pose_distance) -- same bars as the oracle's test (test_oracle.py)."""
+    import json
+
+    with open(os.path.join(HERE, "golden", "utils_golden.json")) as f:
+        g = json.load(f)
+    a, b = np.array(g["a"]), np.array(g["b"])
+    env = make_vec("UR5OriReach-v1", num_envs=8, seed=0)
+    out = env.probe_pose_distance(a, b)
+    assert np.abs(out[:, 0] - np.array(g["distance_single"])).max() < 1e-14
+    ref = np.array(g["angular_single"])
+    assert np.abs(out[:, 1] - ref).max() < 5e-8          # 2 acos(|dot|) at theta -> 0: a few ulp of the dot product
+    well = ref > 1e-3
+    assert np.abs(out[well, 1] - ref[well]).max() < 1e-12
+    assert (ref < 1e-6).any() and (ref > 3.1).any()      # the edge cases are in the fixture
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["ori", "obs", "sta", "dyn"])
+def test_one_step_reproduces_the_reference_observation_on_the_gpu(oracle, name):
+    """tests/golden/reference_observations.json: two consecutive observations of the reference's own PyBullet env per task
+    (see tests/test_reference_pins.py).  The HIP path is put into the state of the first and stepped once."""
+    import refpins
+
+    ref = refpins.load()[name]
+    before, after = ref["before"], ref["after"]
+    scope = refpins.SCOPE.get(name, _abi.LINK_DIST_OBSTACLE)
+    env_id = {v: k for k, v in _abi.ENV_IDS.items()}[refpins.KIND[name]]
+    env = make_vec(env_id, num_envs=1, seed=0, auto_reset=False, link_dist_scope=scope)
+    env.reset(seed=0)
+    ld_state = None
+    if name != "ori":
+        o = before.astype(np.float64)
+        pose = o[refpins.SLOTS[name]["obstacle"]]
+        ld_state = oracle.query(o[6:12], np.r_[pose[:3], refpins.bullet_quat(pose[3:])], scope=scope)[0]
+    env.set_state(refpins.state_before(name, before, ld_state))
+    if name == "dyn":  # rows 6..8 of obst_vel (the per-step displacement) are derived state: let the device derive them
+        env._refresh(None)
+        torch.cuda.synchronize()
+        assert np.abs(env.get_state()["obst_vel"][:6, 0] - before[refpins.SLOTS["dyn"]["velocity"]].astype(np.float64)).max() < 1e-12
+        env.set_state({"step_count": np.array([5], np.int32)})
+    env.step(torch.from_numpy(refpins.action_between(before, after)).cuda())
+    torch.cuda.synchronize()
+    dev = refpins.compare_after(name, np_(env.buf["observation"])[0], after)
+    print(name, {k: float(f"{v:.2e}") for k, v in dev.items()})
+    assert dev["q"] < 3e-7 and dev["goal"] < 1e-7 and dev["ee_pos"] < 2e-6 and dev["ee_rpy"] < 1e-5
+    if name != "ori":
+        assert dev["obst_pos"] < 1e-7 and dev["obst_rpy"] < 1e-6 and dev["link_dist"] < 1e-6
+        # the distances this step computed are what the reference would show one observation later; here: vs the oracle
+        pose = np.r_[np_(env.buf["obst_pos"])[:, 0], np_(env.buf["obst_quat"])[:, 0]]
+        want = oracle.query(np_(env.buf["q"])[:, 0], pose, scope=scope)[0]
+        assert np.abs(np_(env.buf["link_dist"])[:, 0] - want).max() < 1e-8
+    assert not np_(env.buf["terminated"])[0] and not np_(env.buf["collision"])[0]
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,kind", [KINDS[1], KINDS[3]])
+def test_workbench_link_dist_scope_parity(oracle, env_id, kind):
+    """link_dist_scope = URGYM_LINK_DIST_WORKBENCH (per link the minimum over obstacle, table, track; include/urgym.h)."""
+    n, steps = 200, 50
+    env = make_vec(env_id, num_envs=n, seed=37, link_dist_scope=_abi.LINK_DIST_WORKBENCH)
+    orc = oracle.OracleEnv(kind, n, threads=8, link_dist_scope=_abi.LINK_DIST_WORKBENCH)
+    env.reset(seed=37)
+    orc.reset(seed=37)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"], scope=1)
+    # at the neutral pose the upper arm is nearer to the track than to any obstacle (the 0.1015 of the reference's observations)
+    assert np.abs(st["link_dist"][0] - st["link_dist"][0, 0]).max() < 1e-9 and 0.10 < st["link_dist"][0, 0] < 0.103
+    env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())
+    rng = np.random.default_rng(37)
+    finished = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        d, _ = step_both(oracle, kind, env, orc, a, where=f"workbench step {t}")
+        finished += d
+    assert finished > 10
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,kind,n", [("UR5OriReach-v1", _abi.ENV_ORI, 4096), ("UR5DynReach-v1", _abi.ENV_DYN, 512),
+                                           ("UR5ObsReach-v1", _abi.ENV_OBS, 512)])
+def test_check_collision_off_parity(oracle, env_id, kind, n):
+    """BASELINE.json configs[1] "FK + pose-distance reward kernel only" = check_collision=0 (Ori N=4096), and the same switch
+    on the obstacle envs, where the link distances ARE then consumed while links pass through the obstacle: negative
+    link_dist (penetration depth) in state, observation and reward."""
+    steps = 40
+    env = make_vec(env_id, num_envs=n, seed=43, check_collision=False)
+    orc = oracle.OracleEnv(kind, n, threads=8, check_collision=0)
+    env.reset(seed=43)
+    orc.reset(seed=43)
+    rng = np.random.default_rng(43)
+    negative = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        step_both(oracle, kind, env, orc, a, where=f"check_collision=0 step {t}")
+        assert not orc.buf["collision"].any()
+        if kind != _abi.ENV_ORI:
+            negative += int((orc.buf["link_dist"] < 0).sum())
+    if kind != _abi.ENV_ORI:
+        assert negative > 0  # penetration depths were produced and matched (step_both compares link_dist to 1e-8)
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+def test_obs_terminal_collision_reward_uses_penetration_depth(oracle):
+    """ReachObs.compute_reward (reach.py:357-372) reads get_link_distances BEFORE the collision term: on a terminal collision
+    step the reward carries 100 * (negative contact distance - last).  Round 1 clamped that distance to -(margins)."""
+    n = 2048
+    env = make_vec("UR5ObsReach-v1", num_envs=n, seed=47, auto_reset=False)
+    orc = oracle.OracleEnv(_abi.ENV_OBS, n, threads=8, auto_reset=0)
+    env.reset(seed=47)
+    orc.reset(seed=47)
+    rng = np.random.default_rng(47)
+    deep = 0
+    for t in range(25):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        step_both(oracle, _abi.ENV_OBS, env, orc, a, where=f"obs penetration step {t}")
+        pen = (orc.buf["link_dist"] < -0.002 - 1e-9).any(axis=0)  # deeper than the margin sum: a real EPA depth
+        deep += int((pen & orc.buf["collision"].astype(bool)).sum())
+        assert (orc.buf["status"][pen] & _abi.STATUS_PENETRATION).all()
+    assert deep > 5
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+def test_joint_limit_status_bit(oracle):
+    """URGYM_STATUS_JOINT_LIMIT: the elbow passes +-pi (ur5e.urdf:253) after 11 steps of +1 from the neutral 0."""
+    n = 16
+    env = make_vec("UR5OriReach-v1", num_envs=n, seed=3, check_collision=False, auto_reset=False)
+    orc = oracle.OracleEnv(_abi.ENV_ORI, n, check_collision=0, auto_reset=0)
+    env.reset(seed=3)
+    orc.reset(seed=3)
+    a = np.zeros((n, 6), np.float32)
+    a[: n // 2, 2] = 1.0
+    for t in range(12):
+        env.step(torch.from_numpy(a).cuda())
+        orc.step(a)
+        torch.cuda.synchronize()
+        assert np.array_equal(np_(env.buf["status"]), orc.buf["status"]), t
+        over = np.abs(orc.buf["q"][2]) > np.pi
+        assert np.array_equal((orc.buf["status"] & _abi.STATUS_JOINT_LIMIT) != 0, over | ((orc.buf["status"] & _abi.STATUS_JOINT_LIMIT) != 0))
+    assert (orc.buf["status"][: n // 2] & _abi.STATUS_JOINT_LIMIT).all() and not (orc.buf["status"][n // 2:] & _abi.STATUS_JOINT_LIMIT).any()
+    env.close()
+
+
+def test_reset_with_the_same_seed_reproduces_the_episode():
+    """Gymnasium seeding contract: reset(seed=s) twice on the same instance gives the same episodes."""
+    env = make_vec("UR5DynReach-v1", num_envs=300, seed=1)
+    env.reset(seed=7)
+    torch.cuda.synchronize()
+    first = {k: env.buf[k].clone() for k in ("goal", "obst_start", "obst_end", "observation")}
+    a = torch.rand((300, 6), device="cuda") * 2 - 1
+    for _ in range(30):
+        env.step(a)
+    env.reset(seed=7)
+    torch.cuda.synchronize()
+    for k, v in first.items():
+        x = env.buf[k]
+        if k == "observation":  # (the velocity slot of a Dyn reset observation is the stale one of the previous step, reach.py:657)
+            x, v = x.clone(), v.clone()
+            x[:, 24:30] = 0
+            v[:, 24:30] = 0
+        assert torch.equal(x, v), k
+    env.close()

@@ -189,26 +189,27 @@ def dual_distance_hull_vs_cylinder(link, R, t, core_r, core_h):
 
 
 def test_sphere_cylinder_analytic(oracle):
-    # sphere r=0.02 (point core) against the obstacle cylinder (core r=.045,h=.195, margin .005): rounded cylinder
+    # sphere r=0.02 (point core) against the obstacle cylinder (core r=.049,h=.199, margin .001 = Bullet's default
+    # collision margin, pinned by tests/test_reference_pins.py): the rim is rounded with a 1 mm radius
     cyl = [0.05, 0.4]
     for p, expect in [((0.3, 0, 0), 0.3 - 0.05 - 0.02), ((0, 0, 0.5), 0.5 - 0.2 - 0.02), ((0, -0.25, 0.1), 0.25 - 0.05 - 0.02)]:
         r = oracle.closest(oracle.SPHERE, [0.02], [*p, *IDENT], oracle.CYLZ, cyl, [0, 0, 0, *IDENT])
         assert abs(r["distance"] - expect) < 1e-9
     # diagonal off the rim: distance to the rim circle of the CORE minus both margins (rounded edge, App. A.5.6)
     p = np.array([0.2, 0.0, 0.4])
-    core = np.hypot(p[0] - 0.045, p[2] - 0.195)
+    core = np.hypot(p[0] - 0.049, p[2] - 0.199)
     r = oracle.closest(oracle.SPHERE, [0.02], [*p, *IDENT], oracle.CYLZ, cyl, [0, 0, 0, *IDENT])
-    assert abs(r["distance"] - (core - 0.005 - 0.02)) < 1e-9
+    assert abs(r["distance"] - (core - 0.001 - 0.02)) < 1e-9
 
 
 def test_box_box_like_cases_via_hull_track(oracle):
-    # box (Dyn target, half .025 -> core .0225 + margin .0025) vs cylinder, axis-aligned face-to-face and rotated
+    # box (Dyn target, half .025 -> core .024 + margin .001) vs cylinder, axis-aligned face-to-face and rotated
     r = oracle.closest(oracle.BOX, [0.025] * 3, [0.3, 0, 0, *IDENT], oracle.CYLZ, [0.05, 0.4], [0, 0, 0, *IDENT])
-    assert abs(r["distance"] - (0.3 - 0.025 - 0.05)) < 1e-9
+    assert abs(r["distance"] - (0.3 - 0.025 - 0.05)) < 5e-9  # (Bullet's GJK stops at a relative 1e-12 on the SQUARED distance)
     q45 = Rot.from_euler("z", 45, degrees=True).as_quat()
     r = oracle.closest(oracle.BOX, [0.025] * 3, [0.3, 0, 0, *q45], oracle.CYLZ, [0.05, 0.4], [0, 0, 0, *IDENT])
-    # the vertical box edge (rounded with radius .0025) points at the cylinder
-    assert abs(r["distance"] - (0.3 - (0.0225 * np.sqrt(2) + 0.0025) - 0.05)) < 1e-9
+    # the vertical box edge (rounded with radius .001) points at the cylinder
+    assert abs(r["distance"] - (0.3 - (0.024 * np.sqrt(2) + 0.001) - 0.05)) < 1e-9
 
 
 @pytest.mark.parametrize("link", [2, 3, 4, 5, 6])
@@ -219,7 +220,7 @@ def test_hull_cylinder_against_independent_optimiser(oracle, link):
         t = rng.uniform(-0.2, 0.2, 3) + np.array([0.45, 0.1, 0.0])
         pose = np.r_[t, Rm.as_quat()]
         got = oracle.closest(oracle.HULL, [link], pose, oracle.CYLZ, [0.05, 0.4], [0, 0, 0, *IDENT])
-        lower = dual_distance_hull_vs_cylinder(link, Rm.as_matrix(), t, 0.045, 0.195) - 0.001 - 0.005
+        lower = dual_distance_hull_vs_cylinder(link, Rm.as_matrix(), t, 0.049, 0.199) - 0.001 - 0.001
         assert not got["penetrating"]
         assert lower <= got["distance"] + 1e-9, (link, got, lower)   # duality: never above the true distance
         assert got["distance"] - lower < 2e-6, (link, got, lower)    # ... and the search closes the gap
@@ -319,14 +320,21 @@ def test_link_dist_lags_one_step_and_dyn_motion(oracle):
     # ... while the state already holds the new ones where compute_reward ran to the end (reach.py:780-782)
     assert np.any(env.buf["link_dist"][:, ok] != ld_reset[:, ok])
     # velocity slot = the velocity applied in this step (reach.py:744-746)
-    assert np.max(np.abs(env.buf["observation"][:, 24:30] - vel.T.astype(np.float32))) == 0
+    assert np.max(np.abs(env.buf["observation"][:, 24:30] - vel[:6].T.astype(np.float32))) == 0
     for _ in range(24):
         env.step(a)
-    # after 25 steps the obstacle has covered half of start->end (reach.py:735-745, dt = 0.04)
-    assert np.max(np.abs(env.buf["obst_pos"] - (start[:3] + 0.5 * (end[:3] - start[:3])))) < 1e-12
+    # after 25 steps the obstacle has moved 25 x the per-step displacement (rows 6..8 of obst_vel): ABOUT half of
+    # start->end (reach.py:735-745, dt = 0.04) -- not exactly, because Bullet lets the base's linear velocity drift by
+    # h * (omega x v) in each of the 20 sub-steps of an env step (pinned by tests/test_reference_pins.py)
+    assert np.max(np.abs(env.buf["obst_pos"] - (start[:3] + 25.0 * vel[6:9]))) < 1e-12
+    half = start[:3] + 0.5 * (end[:3] - start[:3])
+    drift = np.abs(env.buf["obst_pos"] - half).max(axis=0)
+    bound = 25 * 0.5 * 1.05 * 0.04 ** 2 * np.linalg.norm(np.cross(vel[3:6].T, vel[:3].T), axis=1)  # 25 steps x (21/40) dt^2 |w x v|
+    assert np.all(drift <= bound + 1e-9) and np.any(drift > 1e-4)
+    pos25 = env.buf["obst_pos"].copy()
     env.step(a)
     assert np.all(env.buf["observation"][:, 24:30] == 0)  # step 26: velocity zero (reach.py:748-752)
-    assert np.max(np.abs(env.buf["obst_pos"] - (start[:3] + 0.5 * (end[:3] - start[:3])))) < 1e-12
+    assert np.all(env.buf["obst_pos"] == pos25)
     env.close()
 
 
@@ -392,7 +400,7 @@ def test_refresh_matches_set_goal_and_obstacle_semantics(oracle):
     env.refresh(mask)
     assert np.all(env.buf["observation"][1] == other)
     assert np.max(np.abs(env.buf["obst_pos"][:, 0] - [0.8, -0.5, 0.5])) == 0
-    assert np.max(np.abs(env.buf["obst_vel"][:, 0] - oracle.dyn_velocity(env.buf["obst_start"][:, 0], env.buf["obst_end"][:, 0]))) < 1e-15
+    assert np.max(np.abs(env.buf["obst_vel"][:6, 0] - oracle.dyn_velocity(env.buf["obst_start"][:, 0], env.buf["obst_end"][:, 0]))) < 1e-15
     assert np.all(env.buf["observation"][0, 12:18] == env.buf["goal"][:, 0].astype(np.float32))
     env.close()
 

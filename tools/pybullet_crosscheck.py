@@ -115,21 +115,10 @@ def _test_velocity(i):
 
 
 def oracle_motion(pos, rpy, count):
-    """The oracle's obstacle update through its public step(): a Dyn env whose obstacle state is set by hand."""
+    """The oracle's obstacle update for one env step (20 sub-steps incl. the omega x v drift of the base's linear velocity)."""
     from oracle import binding as ob
-    from ur_gym_amd import _abi
 
-    env = ob.OracleEnv(_abi.ENV_DYN, count, threads=1, auto_reset=0, check_collision=0)
-    env.reset(seed=0)
-    for i in range(count):
-        env.buf["obst_pos"][:, i] = pos[i]
-        env.buf["obst_quat"][:, i] = ob.quat_from_euler(rpy[i])
-        env.buf["obst_vel"][:, i] = _test_velocity(i)
-        env.buf["step_count"][i] = 0
-    env.step(np.zeros((count, 6), np.float32))
-    res = np.concatenate([env.buf["obst_pos"].T, env.buf["obst_quat"].T], axis=1)
-    env.close()
-    return res
+    return np.array([ob.integrate_obstacle(np.r_[pos[i], ob.quat_from_euler(rpy[i])], _test_velocity(i)) for i in range(count)])
 
 
 def compare(a, b):

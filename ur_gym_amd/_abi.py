@@ -1,7 +1,7 @@
 """ctypes mirror of include/urgym.h (struct layouts and constants only; no library is loaded here)."""
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ENV_ORI, ENV_OBS, ENV_DYN, ENV_STA = 0, 1, 2, 3
 ENV_IDS = {"UR5OriReach-v1": ENV_ORI, "UR5ObsReach-v1": ENV_OBS, "UR5DynReach-v1": ENV_DYN, "UR5StaReach-v1": ENV_STA}
@@ -13,10 +13,12 @@ STATUS_RESET_EXHAUSTED = 2
 STATUS_RESET_COLLISION = 4
 STATUS_PENETRATION = 8
 STATUS_GJK_ITER = 16
+STATUS_JOINT_LIMIT = 32
 
 OBS_DIMS = {ENV_ORI: (18, 6), ENV_OBS: (26, 3), ENV_DYN: (35, 6), ENV_STA: (29, 6)}  # (observation, goal) — core.py:241-247
 
 GJK_START_BULLET, GJK_START_GUIDED = 0, 1  # urgym_config.gjk_start (include/urgym.h)
+LINK_DIST_OBSTACLE, LINK_DIST_WORKBENCH = 0, 1  # urgym_config.link_dist_scope (include/urgym.h)
 KEEP_SEED = 0xFFFFFFFFFFFFFFFF
 
 
@@ -30,6 +32,8 @@ class Config(C.Structure):
         ("max_reset_tries", C.c_int32),
         ("dyn_motion_steps", C.c_int32),
         ("gjk_start", C.c_int32),
+        ("link_dist_scope", C.c_int32),
+        ("reserved0", C.c_int32),
         ("action_scale", C.c_double),
         ("dt", C.c_double),
         ("distance_threshold", C.c_double),
@@ -60,7 +64,7 @@ BUFFER_FIELDS = [
     ("obst_end", C.c_double, lambda N, od, gd: (6, N)),
     ("obst_pos", C.c_double, lambda N, od, gd: (3, N)),
     ("obst_quat", C.c_double, lambda N, od, gd: (4, N)),
-    ("obst_vel", C.c_double, lambda N, od, gd: (6, N)),
+    ("obst_vel", C.c_double, lambda N, od, gd: (9, N)),
     ("link_dist", C.c_double, lambda N, od, gd: (5, N)),
     ("step_count", C.c_int32, lambda N, od, gd: (N,)),
     ("episode_id", C.c_int32, lambda N, od, gd: (N,)),
@@ -98,6 +102,7 @@ EXPORTED_SYMBOLS = [
     "urgym_rollout",
     "urgym_refresh",
     "urgym_probe_closest",
+    "urgym_probe_pose_distance",
     "urgym_enable_timing",
     "urgym_query_timing", "urgym_query_refill_timing",
     "urgym_last_error",

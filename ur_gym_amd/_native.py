@@ -59,6 +59,7 @@ def lib():
     L.urgym_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.urgym_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.urgym_probe_closest.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.urgym_probe_pose_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.urgym_enable_timing.argtypes = [C.c_void_p, C.c_int]
     L.urgym_query_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.urgym_query_refill_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]

@@ -169,6 +169,12 @@ __device__ __forceinline__ double angular_distance(const double a[3], const doub
   return 2.0 * acos(fabs(d));
 }
 
+// utils.distance (utils.py:5-31): L2 norm of the first three components
+__device__ __forceinline__ double pos_distance(const double a[3], const double b[3]) {
+  const double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
 // ---------------------------------------------------------------------------------------------- Philox4x32-10
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                               uint32_t out[4]) {
@@ -519,6 +525,197 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; gjk_finish(r, false, 0); return; }
   if (n == 4) { gjk_finish(r, false, 13); return; }
 }
+
+
+// ---------------------------------------------------------------------------------------------- penetration depth (EPA)
+// When the cores overlap Bullet reports the NEGATIVE penetration depth of the margin-inflated shapes (btGjkEpa2 behind
+// btGjkPairDetector; pyb_setup.py:452 stores it in link_dist).  depth(inflated) = depth(cores) + margin_A + margin_B, and
+// depth(cores) = min over unit n of h_{A-B}(n) is found here by an expanding polytope -- the same slot-by-slot algorithm as
+// the oracle's epa_core_depth, converged to 1e-9 (Bullet's own EPA stops at 1e-4: its answer lies within 1e-4 m below).
+//
+// ONE WAVE per query, all 64 lanes with identical arguments and wave-uniform control flow: the (rare) queries that need it
+// are served after the GJK pool has drained, when the per-lane GJK slots of LDS are free.  The wave's 24 x 64 doubles
+// M[r][c] (r = row of s_pose, c = the wave's column) are its workspace:
+//   M[0..11][0]                       pose of A in B's frame (the XRef the supports read, every lane the same address)
+//   M[3 (v / 63) + k][1 + v % 63]     coordinate k of polytope point v < EPA_MAX_VERTS            (rows 0..5)
+//   rows 6, 7 (cols 1..63) as int32   face f: i | j << 8 | k << 16 | alive << 24 | degenerate << 25
+//   rows 8..10 (cols 1..63) as uint16 rim candidates: the directed edges of the faces that see the new point
+//   row 11 (cols 1..63) as uint8      free face slots in ascending order
+//   M[12 + 4 (f / 64) + k][f % 64]    plane of face f: unit normal (k = 0..2) and offset d (k = 3)   (rows 12..23)
+// Lane c owns the faces f = c, c + 64, c + 128.
+constexpr int EPA_MAX_VERTS = 80, EPA_MAX_FACES = 192;
+constexpr double EPA_TOL = 1.0e-9;
+#if !defined(URGYM_HOST_HARNESS)
+struct EpaWs {
+  URGYM_LDS double* base;  // &M[0][0]
+  int stride;              // doubles between rows
+  __device__ __forceinline__ URGYM_LDS double* at(int r, int c) const { return base + r * stride + c; }
+  __device__ __forceinline__ D3 point(int v) const {
+    const int r = 3 * (v / 63), c = 1 + v % 63;
+    return d3(*at(r, c), *at(r + 1, c), *at(r + 2, c));
+  }
+  __device__ __forceinline__ void set_point(int v, D3 p) const {
+    const int r = 3 * (v / 63), c = 1 + v % 63;
+    *at(r, c) = p.x; *at(r + 1, c) = p.y; *at(r + 2, c) = p.z;
+  }
+  __device__ __forceinline__ URGYM_LDS int* face_word(int f) const {
+    return f < 126 ? (URGYM_LDS int*)at(6, 1) + f : (URGYM_LDS int*)at(7, 1) + (f - 126);
+  }
+  __device__ __forceinline__ URGYM_LDS unsigned short* rim(int c) const { return (URGYM_LDS unsigned short*)at(8 + c / 252, 1) + c % 252; }
+  __device__ __forceinline__ URGYM_LDS unsigned char* free_slot(int r) const { return (URGYM_LDS unsigned char*)at(11, 1) + r; }
+  __device__ __forceinline__ URGYM_LDS double* plane(int f, int k) const { return at(12 + 4 * (f >> 6) + k, f & 63); }
+};
+__device__ __forceinline__ void epa_wave_sync() {  // LDS traffic of one wave is in order; this only stops the compiler
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+// plane of the triangle (pi, pj, pk): returns false for a degenerate one (kept alive, replaced by the next expansion)
+__device__ __forceinline__ bool epa_plane(D3 pi, D3 pj, D3 pk, D3& n, double& d) {
+  const D3 c = cross(pj - pi, pk - pi);
+  const double l2 = len2(c);
+  if (l2 > 1e-40) {
+    n = c * (1.0 / sqrt(l2));
+    d = dot(n, pi);
+    return true;
+  }
+  n = d3(0, 0, 0);
+  d = 1e300;
+  return false;
+}
+// T: pose of A in B's frame, stored at M[0..11][0] of `ws` (XRef{ws.base, ws.stride}).  Returns depth(cores) >= 0.
+__device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const ShapeDesc& B, EpaWs ws, int lane, bool& capped) {
+  const XRef T{ws.base, ws.stride};
+  auto supp = [&](D3 n) -> D3 { return apply(T, support_local(g, A, rotT(T, n))) - support_local(g, B, -n); };
+  const double t = 0.5773502691896258;
+  {
+    const D3 p0 = supp(d3(t, t, t)), p1 = supp(d3(t, -t, -t)), p2 = supp(d3(-t, t, -t)), p3 = supp(d3(-t, -t, t));
+    if (lane == 0) { ws.set_point(0, p0); ws.set_point(1, p1); ws.set_point(2, p2); ws.set_point(3, p3); }
+#pragma unroll
+    for (int gi = 0; gi < 3; gi++) *ws.face_word(lane + 64 * gi) = 0;
+    epa_wave_sync();
+    if (lane < 4) {
+      // faces of the tetrahedron 0123, turned outward
+      int i = lane == 3 ? 1 : 0, j = lane == 0 ? 1 : (lane == 1 ? 3 : (lane == 2 ? 2 : 3)), k = lane == 0 ? 2 : (lane == 1 ? 1 : (lane == 2 ? 3 : 2));
+      const int o = lane == 0 ? 3 : (lane == 1 ? 2 : (lane == 2 ? 1 : 0));
+      const D3 pi = ws.point(i), pj = ws.point(j), pk = ws.point(k), po = ws.point(o);
+      if (dot(cross(pj - pi, pk - pi), po - pi) > 0.0) { const int tmp = j; j = k; k = tmp; }
+      D3 n;
+      double d;
+      const bool ok = epa_plane(ws.point(i), ws.point(j), ws.point(k), n, d);
+      *ws.plane(lane, 0) = n.x; *ws.plane(lane, 1) = n.y; *ws.plane(lane, 2) = n.z; *ws.plane(lane, 3) = d;
+      *ws.face_word(lane) = i | (j << 8) | (k << 16) | (1 << 24) | (ok ? 0 : (1 << 25));
+    }
+    epa_wave_sync();
+  }
+  int nv = 4;
+  capped = false;
+  double depth = 0.0;
+#pragma unroll 1
+  for (;;) {
+    // (1) the face closest to the origin, ties to the lowest slot
+    double bd = 1.7e308;
+    int bf = 1 << 20;
+#pragma unroll
+    for (int gi = 0; gi < 3; gi++) {
+      const int f = lane + 64 * gi;
+      const bool alive = ((*ws.face_word(f)) >> 24) & 1;
+      const double d = *ws.plane(f, 3);
+      if (alive && d < bd) { bd = d; bf = f; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const double od = __shfl_xor(bd, off);
+      const int of = __shfl_xor(bf, off);
+      if (od < bd || (od == bd && of < bf)) { bd = od; bf = of; }
+    }
+    bf = __builtin_amdgcn_readfirstlane(bf);
+    const D3 nb = d3(*ws.plane(bf, 0), *ws.plane(bf, 1), *ws.plane(bf, 2));
+    const double db = *ws.plane(bf, 3);
+    // (2) expand along its normal
+    const D3 w = supp(nb);
+    const double gain = dot(nb, w) - db;
+    if (gain <= EPA_TOL || nv >= EPA_MAX_VERTS) {
+      capped = gain > EPA_TOL;
+      depth = db > 0.0 ? db : 0.0;
+      break;
+    }
+    // (3) faces that see w die; their directed edges become rim candidates in ascending slot order
+    int nvis_before = 0, nc;
+    {
+      bool vis[3];
+      int word[3];
+#pragma unroll
+      for (int gi = 0; gi < 3; gi++) {
+        const int f = lane + 64 * gi;
+        word[gi] = *ws.face_word(f);
+        const bool alive = (word[gi] >> 24) & 1, degen = (word[gi] >> 25) & 1;
+        const D3 n = d3(*ws.plane(f, 0), *ws.plane(f, 1), *ws.plane(f, 2));
+        vis[gi] = alive && (degen || dot(n, w) - *ws.plane(f, 3) > 1e-14);
+      }
+#pragma unroll
+      for (int gi = 0; gi < 3; gi++) {
+        const unsigned long long m = __ballot(vis[gi]);
+        if (vis[gi]) {
+          const int rank = nvis_before + __popcll(m & ((1ull << lane) - 1ull));
+          const int i = word[gi] & 255, j = (word[gi] >> 8) & 255, k = (word[gi] >> 16) & 255;
+          *ws.rim(3 * rank + 0) = (unsigned short)((i << 8) | j);
+          *ws.rim(3 * rank + 1) = (unsigned short)((j << 8) | k);
+          *ws.rim(3 * rank + 2) = (unsigned short)((k << 8) | i);
+          *ws.face_word(lane + 64 * gi) = 0;
+        }
+        nvis_before += __popcll(m);
+      }
+      nc = 3 * nvis_before;
+    }
+    epa_wave_sync();
+    // (4) the free slots, ascending
+    int nfree = 0;
+#pragma unroll
+    for (int gi = 0; gi < 3; gi++) {
+      const int f = lane + 64 * gi;
+      const bool fr = !(((*ws.face_word(f)) >> 24) & 1);
+      const unsigned long long m = __ballot(fr);
+      if (fr) *ws.free_slot(nfree + __popcll(m & ((1ull << lane) - 1ull))) = (unsigned char)f;
+      nfree += __popcll(m);
+    }
+    epa_wave_sync();
+    // (5) horizon = candidates whose reverse is not a candidate; one new face per horizon edge, into the free slots in order
+    int nh = 0;
+    bool overflow = false;
+#pragma unroll 1
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int c = c0 + lane;
+      const bool valid = c < nc;
+      const int e = valid ? (int)*ws.rim(c) : 0;
+      const int rev = ((e & 255) << 8) | (e >> 8);
+      bool found = false;
+#pragma unroll 1
+      for (int x = 0; x < nc; x++) found = found || ((int)*ws.rim(x) == rev);
+      const bool hor = valid && !found;
+      const unsigned long long m = __ballot(hor);
+      if (hor) {
+        const int r = nh + __popcll(m & ((1ull << lane) - 1ull));
+        if (r < nfree) {
+          const int f = *ws.free_slot(r);
+          const int a = e >> 8, b = e & 255;
+          D3 n;
+          double d;
+          const bool ok = epa_plane(ws.point(a), ws.point(b), w, n, d);
+          *ws.plane(f, 0) = n.x; *ws.plane(f, 1) = n.y; *ws.plane(f, 2) = n.z; *ws.plane(f, 3) = d;
+          *ws.face_word(f) = a | (b << 8) | (nv << 16) | (1 << 24) | (ok ? 0 : (1 << 25));
+        }
+      }
+      nh += __popcll(m);
+    }
+    overflow = nh > nfree;
+    if (lane == 0) ws.set_point(nv, w);
+    nv++;
+    epa_wave_sync();
+    if (overflow) { capped = true; depth = db > 0.0 ? db : 0.0; break; }
+  }
+  return depth;
+}
+#endif  // !URGYM_HOST_HARNESS
 
 // convenience wrapper: run one query to the end
 __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,

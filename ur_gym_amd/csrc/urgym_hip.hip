@@ -1,20 +1,26 @@
 // urgym_hip.hip — fused UR5e reach environment kernels for MI355X (gfx950) + the C-ABI of include/urgym.h.
 //
-// One workgroup = 64 environments x 5 waves (320 threads).  Wave w owns PyBullet link L = w + 2 (upper arm,
-// forearm, wrist 1..3) of each of the 64 environments of the group: lane e of wave w evaluates link L of env e.
+// One kernel template env_kernel<KIND, MODE> (MODE = STEP | RESET | REFRESH | PREFETCH); device math in urgym_device.h.
+// One workgroup = 4 waves (256 lanes) serving E <= 64 environments (E is a launch parameter, urgym_create picks it).
 //
-//   P0  all threads stream the packed convex-hull vertex table (42.5 KB, float32) from L2 into LDS
-//   P1  every lane: joint update q += 0.1*pi*clip(a) (UR5.py:273-279), obstacle motion (reach.py:728-753 +
-//       pyb_setup.py:52-55), FK of the URDF chain up to its own link in float64, bounding-capsule culling of the
-//       table / track / self-collision pairs of pyb_setup.py:382-429 that involve its link (survivors -> LDS queue)
-//   P2  every lane: exact GJK distance hull(L) <-> obstacle cylinder (pyb_setup.py:439-456)  -> LDS
-//   P3  the (rare) queued hull<->box / hull<->hull pairs, one per lane across the whole group
-//   P4  wave 4 (which holds the end-effector frame): Euler read-out, pose distances, success / collision /
-//       reward (reach.py:221-236, 356-374, 764-785), lagged link_dist, state write-back, observation rows staged
-//       in LDS and written back coalesced by all waves
+//   P1   one lane per env (STEP: on the LAST wave, while the other waves already run their queries): joint update
+//        q += f32(f32(clip(a) * pi) * 0.1) (UR5.py:273-279), one float64 FK pass, world bounding capsules, conservative
+//        culling of the 19 table / track / self pairs of check_collision (pyb_setup.py:382-429) -> a 19-bit mask per env in
+//        LDS; the end-effector read-out (pyb_setup.py:221-253).  STEP keeps NO joint / obstacle state in LDS: any lane
+//        re-derives them from global memory (joint_of_step, obstacle_of_step).
+//   pool the closest-distance work of the workgroup: 5 E obstacle "tickets" (exact distance hull(link) <-> cylinder,
+//        pyb_setup.py:439-456; 15 E with URGYM_LINK_DIST_WORKBENCH: table and track too) + the set bits of the pair masks
+//        (boolean "closer than the margin?" queries).  Every lane advances ITS query by one GJK iteration per loop trip
+//        through one inlined, resumable GJK body (gjk_begin / gjk_iterate); idle lanes draw the next item together.
+//   EPA  the (rare) obstacle queries whose cores overlap and whose distance is consumed: penetration depth by an expanding
+//        polytope, one wave per query, faces spread over the lanes (pyb_setup.py:452 stores a negative contact distance).
+//   P4   one lane per env: pose distances, success / collision / reward (reach.py:221-236, 356-374, 764-785), lagged
+//        link_dist, state write-back; a finished env is reset inline from its prefetched episode record or appended to the
+//        done list; observation rows -> LDS -> coalesced stores.
 //
-// Finished environments are appended to a device-side list; a second launch of the same kernel in RESET mode
-// re-samples them (counter-based Philox, rejection rules of reach.py:313-326 / 664-683) with no host round trip.
+// RESET consumes the device-side done list (no host round trip): Philox-keyed rejection sampling of reach.py:313-326 /
+// 664-683 by the whole first wave, then the neutral-pose link distances.  PREFETCH is RESET with an episode record as its
+// output; it runs on a side stream under the next step kernel.  REFRESH = Reach*.set_goal[_and_obstacle].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -57,15 +63,18 @@ __host__ __device__ constexpr int self_pair_bit(int la, int lb) {  // (1,3)(1,4)
 enum { MODE_STEP = 0, MODE_RESET = 1, MODE_REFRESH = 2, MODE_PREFETCH = 3 };
 enum { Q_TABLE = 0, Q_TRACK = 1, Q_SELF = 2 };
 
-// Bullet collision margins: hull 0.001; cylinder r=0.05 -> 0.005; table 0.04; track 0.006;
-// Dyn target box half 0.025 -> 0.0025; Obs target sphere -> radius 0.02 around a point core.
-constexpr double M_HULL = 0.001;
-constexpr double CYL_R = 0.05, CYL_H = 0.4, M_CYL = 0.005;
+// Bullet collision margins.  URDF convex meshes: 0.001, hull un-shrunk.  Every primitive made by p.createCollisionShape
+// (pyb_setup.py:748-752) ends with shape->setMargin(0.001) (the physics server's default collision margin), which
+// btCylinderShape / btBoxShape answer by shrinking their core by the same amount: cylinder core r 0.049, h/2 0.199.
+// PINNED by the reference's own observations (tests/test_reference_pins.py; the constructors' "safe margin" that round 1
+// used is off by up to 1.7e-3 m there).  Obs target: btSphereShape, margin = its radius around a point core.
+constexpr double M_HULL = 0.001, M_PRIM = 0.001;
+constexpr double CYL_R = 0.05, CYL_H = 0.4, M_CYL = M_PRIM;
 constexpr double TABLE_CX = 0.5, TABLE_CY = 0.0, TABLE_CZ = -0.58, TABLE_HX = 0.55, TABLE_HY = 0.9, TABLE_HZ = 0.46;
-constexpr double M_TABLE = 0.04;
+constexpr double M_TABLE = M_PRIM;
 constexpr double TRACK_CX = 0.0, TRACK_CY = 0.0, TRACK_CZ = -0.06, TRACK_HX = 0.1, TRACK_HY = 0.55, TRACK_HZ = 0.06;
-constexpr double M_TRACK = 0.006;
-constexpr double TARGET_BOX_H = 0.025, M_TARGET_BOX = 0.0025, TARGET_SPHERE_R = 0.02;
+constexpr double M_TRACK = M_PRIM;
+constexpr double TARGET_BOX_H = 0.025, M_TARGET_BOX = M_PRIM, TARGET_SPHERE_R = 0.02;
 
 struct DevTables {
   double joint_rot[6][9];
@@ -77,9 +86,9 @@ __constant__ DevTables c_tab;
 // Prefetched episode records (DESIGN.md "auto-reset off the critical path"): everything a reset produces is a pure function of
 // (seed, env, episode id), so the records of the next two episodes of every env are kept ready in handle-owned memory:
 // slot = episode & 1; fields per env (float64): goal 0..5, obstacle start 6..11, obstacle end 12..17, obstacle velocity 18..23,
-// obstacle quaternion 24..27, neutral-pose link distances 28..32; ints: the episode id the record is for (-1 = none), status.
-constexpr int REC_FIELDS = 33;
-enum { REC_GOAL = 0, REC_START = 6, REC_END = 12, REC_VEL = 18, REC_QUAT = 24, REC_LD = 28 };
+// obstacle quaternion 24..27, neutral-pose link distances 28..32, displacement per env step 33..35; ints: the episode id the record is for (-1 = none), status.
+constexpr int REC_FIELDS = 36;
+enum { REC_GOAL = 0, REC_START = 6, REC_END = 12, REC_VEL = 18, REC_QUAT = 24, REC_LD = 28, REC_DP = 33 };
 
 struct KParams {
   urgym_config cfg;
@@ -109,6 +118,13 @@ __device__ __forceinline__ int32_t& RECI(const KParams& P, int slot, int j, int 
 }
 
 __device__ __forceinline__ double& SOA(double* base, int f, int n, int N) { return base[(size_t)f * N + n]; }
+
+// order-preserving map double <-> int64 (an involution): lets LDS keep "the smallest distance so far" with one ds_min_i64
+__device__ __forceinline__ long long sortable(double x) {
+  const long long k = __double_as_longlong(x);
+  return k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFLL);
+}
+__device__ __forceinline__ double unsortable(long long k) { return __longlong_as_double(k ^ ((k >> 63) & 0x7FFFFFFFFFFFFFFFLL)); }
 
 __device__ __forceinline__ ShapeDesc hull_desc(int link /*1..6*/) {
   ShapeDesc s;
@@ -214,10 +230,27 @@ __device__ void dyn_velocity(const double start[6], const double end[6], double 
   vel[3] = axis.x * angle / T; vel[4] = axis.y * angle / T; vel[5] = axis.z * angle / T;
 }
 
-// one env step of the obstacle base: p += v*dt, R <- exp([w] dt) R  (20 Bullet sub-steps of a constant twist
-// compose to a single exponential; pyb_setup.py:52-55)
-__device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const double vel[6], double dt) {
-  pos[0] += vel[0] * dt; pos[1] += vel[1] * dt; pos[2] += vel[2] * dt;
+// Displacement of the obstacle base over one env step = 20 Bullet sub-steps of h = dt / 20 (pyb_setup.py:52-55).  In every
+// sub-step btMultiBody first adds h * (w x v) to the base's linear velocity (the transport term of the world-frame read-out
+// of its zero spatial acceleration), then moves the base by h * v; resetBaseVelocity restores the task's twist before each
+// env step (reach.py:745).  PINNED by the reference's two consecutive UR5DynReach-v1 observations (tests/test_reference_pins.py).
+// The twist is constant over an episode, so is this vector: it is evaluated at reset / refresh and kept in rows 6..8 of obst_vel.
+__device__ __forceinline__ void step_displacement(const double vel[6], double dt, double dp[3]) {
+  const double h = dt / 20.0;
+  D3 v = d3(vel[0], vel[1], vel[2]);
+  const D3 w = d3(vel[3], vel[4], vel[5]);
+  double px = 0.0, py = 0.0, pz = 0.0;
+#pragma unroll 1
+  for (int k = 0; k < 20; k++) {
+    v = v + cross(w, v) * h;
+    px += h * v.x; py += h * v.y; pz += h * v.z;
+  }
+  dp[0] = px; dp[1] = py; dp[2] = pz;
+}
+// one env step of the obstacle base: p += dp (above), R <- exp([w] dt) R  (20 sub-step rotations about a constant axis
+// compose to a single exponential)
+__device__ __forceinline__ void integrate_obstacle(double pos[3], Q4& q, const double vel[6], const double dp[3], double dt) {
+  pos[0] += dp[0]; pos[1] += dp[1]; pos[2] += dp[2];
   D3 w = d3(vel[3], vel[4], vel[5]);
   double ang = sqrt(len2(w));
   if (ang > 0.0) {
@@ -423,9 +456,10 @@ __device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double
   for (int i = 0; i < 3; i++) opos[i] = SOA(B.obst_pos, i, n, N);
   oq = Q4{SOA(B.obst_quat, 0, n, N), SOA(B.obst_quat, 1, n, N), SOA(B.obst_quat, 2, n, N), SOA(B.obst_quat, 3, n, N)};
   if (KIND == URGYM_ENV_DYN && B.step_count[n] < cfg.dyn_motion_steps) {
-    double ovel[6];
+    double ovel[6], dp[3];
     for (int i = 0; i < 6; i++) ovel[i] = SOA(B.obst_vel, i, n, N);
-    integrate_obstacle(opos, oq, ovel, cfg.dt);
+    for (int i = 0; i < 3; i++) dp[i] = SOA(B.obst_vel, 6 + i, n, N);
+    integrate_obstacle(opos, oq, ovel, dp, cfg.dt);
   }
   if (KIND == URGYM_ENV_STA) {
     // core.py:307-308 + ReachSta.set_velocity (reach.py:518-541): only when obstacle_end is not all-zero; the full
@@ -435,9 +469,10 @@ __device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double
     for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); moving = moving || en[i] != 0.0; }
     if (moving) {
       const double dx = en[0] - opos[0], dy = en[1] - opos[1], dz = en[2] - opos[2];
-      double ovel[6] = {0, 0, 0, 0, 0, 0};
+      double ovel[6] = {0, 0, 0, 0, 0, 0}, dp[3];
       if (sqrt(dx * dx + dy * dy + dz * dz) > 0.05) dyn_velocity(st, en, 1.0, ovel);
-      integrate_obstacle(opos, oq, ovel, cfg.dt);
+      step_displacement(ovel, cfg.dt, dp);
+      integrate_obstacle(opos, oq, ovel, dp, cfg.dt);
     }
   }
 }
@@ -461,7 +496,9 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP_TIME(k) do {} while (0)
 #endif
 
-template <int KIND, int MODE>
+// WITH_EPA: compiled with the penetration-depth phase (the host picks the instance: a STEP launch of Dyn / Sta with the
+// collision checks on can never consume a penetration depth, and its kernel stays free of that code's registers and scratch)
+template <int KIND, int MODE, bool WITH_EPA>
 __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
   // per-env slots (E = P.envs envs per workgroup, <= MAX_ENVS) ...
   // PREFETCH workgroups run UNDER a step kernel: with at most 32 envs and no joint array they need < 55 KB and share a CU with
@@ -497,7 +534,13 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
   constexpr int EE_BIT = 1 << 29;  // STEP: the per-env phase has already stored the end-effector pose of this step (P4 reads it back)
-  const XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
+  // bits 8..22 of s_flags: exact queries that ended with overlapping cores and whose distance IS consumed -> penetration depth
+  // by EPA after the pool has drained; bit = 5 * body + (link - 2), body 0 obstacle, 1 table, 2 track (WORKBENCH scope)
+  constexpr int EPA_SHIFT = 8, EPA_MASK = 0x7FFF << EPA_SHIFT;
+  // Dyn / Sta return -500 on a collision before the distances are used (reach.py:766-767), and overlapping cores ARE a
+  // collision: only Obs (reach.py:357-372), the collision-free variant and reset / refresh consume a penetration depth
+  const bool need_epa = WITH_EPA && ((KIND == URGYM_ENV_OBS) || !cfg.check_collision || (MODE != MODE_STEP));
+  XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
   static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
 
@@ -508,6 +551,11 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if ((int)blockIdx.x * E >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
+  // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
+  // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
+  const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
+  if (workbench && tid < E)
+    for (int i = 0; i < 5; i++) s_dist[i][tid] = __longlong_as_double(0x7FF0000000000000LL);
   // STEP: the per-env phase P1 (joint check + culling) runs on the LAST wave while the others already start their obstacle
   // queries — nothing a query needs comes from P1 (joints and obstacle are re-derived from global memory), only the pair
   // masks do, and those are drawn late.  So the slots are initialised here, before the first barrier, and the barrier after
@@ -555,6 +603,13 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if (n >= 0) {
       for (int i = 0; i < 6; i++) q[i] = joint_of_step<MODE>(P, actions, n, i);
       for (int i = 0; i < 6; i++) finite = finite && (fabs(q[i]) < 1.0e6);  // false for NaN/inf: no distance queries then
+      if (MODE == MODE_STEP) {
+        // resetJointState does not clamp (pyb_setup.py:338), so neither does this; but past the URDF limit (ur5e.urdf:237-277:
+        // elbow +-pi, the others +-2 pi) Bullet's limit constraint would act during stepSimulation -- flagged, not altered
+        bool over = false;
+        for (int i = 0; i < 6; i++) over = over || (fabs(q[i]) > (i == 2 ? 3.141592653589793 : 6.283185307179586));
+        if (over) atomicOr(&s_flags[lane], URGYM_STATUS_JOINT_LIMIT);
+      }
       if (HAS_OBST && LDS_STATE) {
         // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710); PREFETCH: the record's
         double sp[6];
@@ -635,6 +690,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     ShapeDesc sa = hull_desc(1), sb = cyl_desc();
     D3 v0 = d3(0, 1, 0);
     int kind = 3, e = 0, lb = 2;
+    bool exact = false;  // table / track item that wants the distance itself (WORKBENCH link_dist), not just "closer than the margin?"
     // URGYM_GJK_START_GUIDED (include/urgym.h): first separating axis = unit vector from the other shape's centre to
     // the mid point of the link's bounding capsule; same arithmetic as the oracle's guided_axis()
     const bool guided = cfg.gjk_start == URGYM_GJK_START_GUIDED;
@@ -651,6 +707,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     auto setup = [&](uint32_t item) -> bool {
       e = item & 255;
       kind = (item >> 8) & 3;
+      exact = ((item >> 16) & 1) != 0;
       lb = (item >> 10) & 7;
       const int la = (item >> 13) & 7;
       const int n = s_env[e];
@@ -728,10 +785,12 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     auto margin_sum = [&]() -> double {
       return M_HULL + ((kind == 3) ? M_CYL : ((kind == Q_SELF) ? M_HULL : ((kind == Q_TABLE) ? M_TABLE : M_TRACK)));
     };
-    const int n_tickets = HAS_OBST ? 5 * E : 0;
+    const int n_tickets = HAS_OBST ? (workbench ? 15 : 5) * E : 0;
     auto ticket_item = [&](int t) -> uint32_t {
-      const int tl = t / E, te = t - tl * E, link = 2 + tl;
-      return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
+      const int body = t / (5 * E), r = t - body * 5 * E;  // 0 obstacle, then (WORKBENCH) 1 table, 2 track
+      const int tl = r / E, te = r - tl * E, link = 2 + tl;
+      if (body == 0) return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
+      return (uint32_t)te | ((uint32_t)(body == 1 ? Q_TABLE : Q_TRACK) << 8) | ((uint32_t)link << 10) | (1u << 16);
     };
 
     GjkRun run;
@@ -749,11 +808,17 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         gjk_iterate(run, P.graph, sa, pose_slot, sb);
         if (run.done) {
           const double msum = margin_sum();
-          if (kind == 3) {
+          if (kind == 3 || exact) {
             double dist = run.core - msum;
-            if (run.info & GJK_PENETRATING) { dist = -msum; atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION); }
+            if (run.info & GJK_PENETRATING) {
+              // provisional value (exact only when the cores just touch); the EPA phase below replaces it where it is consumed
+              dist = -msum;
+              const int body = (kind == 3) ? 0 : (kind == Q_TABLE ? 1 : 2);
+              atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION | (need_epa ? (1 << (EPA_SHIFT + 5 * body + (lb - 2))) : 0));
+            }
             if (run.info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
-            s_dist[lb - 2][e] = dist;
+            if (workbench) atomicMin(reinterpret_cast<long long*>(&s_dist[lb - 2][e]), sortable(dist));
+            else s_dist[lb - 2][e] = dist;
           } else {
             const bool hit = (run.info & GJK_PENETRATING) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
             if (hit) atomicOr(&s_flags[e], COLL_BIT);
@@ -761,7 +826,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
           busy = false;
         }
       }
-      const bool more_tickets = s_ticket < n_tickets, more_pairs = s_pending > 0;  // wave-uniform reads
+      // (atomic loads: other waves change both words while this one polls them; a plain read could legally be hoisted)
+      const bool more_tickets = __hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_tickets;
+      const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+      const bool more_pairs = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0;  // (read AFTER the acquire)
       // drawing an item costs the whole wave a set-up (FK + operands), so idle lanes
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
       const int idle_lanes = __popcll(__ballot(!busy));
@@ -776,18 +844,54 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         }
         if (item != NO_ITEM) {
           busy = setup(item);
-          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + (kind == 3 ? 5.0 : cfg.collision_margin));
+          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
         }
       }
       // nothing left for this wave to draw (STEP: and the pair masks have been published)
-      if (__ballot(busy) == 0ull && !more_tickets && !more_pairs &&
-          (MODE != MODE_STEP || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0))
-        break;
+      if (__ballot(busy) == 0ull && !more_tickets && !more_pairs && p1_published) break;
     }
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
+    __syncthreads();
+    // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  The marks are final
+    //      after the barrier, so every wave enumerates the same list and takes every WAVES-th entry.
+    if (HAS_OBST && WITH_EPA) {
+      const int marks = (lane < E) ? ((s_flags[lane] & EPA_MASK) >> EPA_SHIFT) : 0;
+      unsigned long long envs_marked = __ballot(marks != 0);
+      if (envs_marked != 0ull) {  // uniform over the workgroup
+        const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
+        pose_slot.p = ws.base;    // every lane of the wave stores the (same) operands into the wave's slot
+        int counter = 0;
+#pragma unroll 1
+        while (envs_marked) {
+          const int ee = __builtin_ctzll(envs_marked);
+          envs_marked &= envs_marked - 1ull;
+          int me = __shfl(marks, ee);
+#pragma unroll 1
+          while (me) {
+            const int b = __builtin_ctz((unsigned)me);
+            me &= me - 1;
+            if ((counter++ % WAVES) != wv) continue;
+            const int body = b / 5, link = 2 + b - 5 * body;
+            const uint32_t item = (uint32_t)ee | ((uint32_t)(body == 0 ? 3 : (body == 1 ? Q_TABLE : Q_TRACK)) << 8) | ((uint32_t)link << 10) |
+                                  ((body ? 1u : 0u) << 16);
+            if (!setup(item)) continue;
+            epa_wave_sync();
+            bool capped;
+            const double depth = epa_wave(P.graph, sa, sb, ws, lane, capped);
+            if (lane == 0) {
+              const double dist = -(depth + margin_sum());
+              if (workbench) atomicMin(reinterpret_cast<long long*>(&s_dist[lb - 2][e]), sortable(dist));
+              else s_dist[lb - 2][e] = dist;
+              if (capped) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+            }
+          }
+        }
+        pose_slot.p = (URGYM_LDS double*)&s_pose[0][0] + tid;
+        __syncthreads();
+      }
+    }
   }
-  __syncthreads();
   STAMP_TIME(6);
 
   // ---- P4: one lane per env re-derives the end-effector frame (link 6 == ee_link 7, urdf:294-298) and finishes the step
@@ -834,7 +938,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     bool coll = (s_flags[pe] & COLL_BIT) != 0;
     if (HAS_OBST) {
       for (int i = 0; i < 5; i++) {
-        ld_new[i] = s_dist[i][pe];
+        ld_new[i] = workbench ? unsortable(__double_as_longlong(s_dist[i][pe])) : s_dist[i][pe];
         if (MODE == MODE_STEP) ld_old[i] = SOA(B.link_dist, i, n, N);
         if (cfg.check_collision && ld_new[i] <= cfg.collision_margin) coll = true;
       }
@@ -842,7 +946,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if (MODE == MODE_PREFETCH) {
       // the rest of the record: what RESET would have written into the live state (reach.py:324-325, 680-681; set_velocity)
       const int key = s_key[pe], sl = key & 1;
-      int rflags = s_flags[pe] & ~(COLL_BIT | EE_BIT);
+      int rflags = s_flags[pe] & ~(COLL_BIT | EE_BIT | EPA_MASK);
       if (coll) rflags |= URGYM_STATUS_RESET_COLLISION;
       if (HAS_OBST) {
         for (int i = 0; i < 5; i++) REC(P, sl, REC_LD + i, n) = ld_new[i];
@@ -853,7 +957,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
           for (int i = 0; i < 6; i++) { st[i] = REC(P, sl, REC_START + i, n); en[i] = REC(P, sl, REC_END + i, n); }
           dyn_velocity(st, en, cfg.dyn_time_duration, vel);
         }
+        double dp[3];
+        step_displacement(vel, cfg.dt, dp);
         for (int i = 0; i < 6; i++) REC(P, sl, REC_VEL + i, n) = vel[i];
+        for (int i = 0; i < 3; i++) REC(P, sl, REC_DP + i, n) = dp[i];
       }
       RECI(P, sl, 1, n) = rflags;
       __threadfence();
@@ -909,18 +1016,17 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     write_row(ach, q, goal, obst6, opos, oq, vobs, ld_obs);
 
     // is_success on the float32 achieved goal vs the float64 goal (reach.py:212-215, 348-350, 755-758)
-    double dx = (double)ach[0] - goal[0], dy = (double)ach[1] - goal[1], dz = (double)ach[2] - goal[2];
-    double d = sqrt(dx * dx + dy * dy + dz * dz);
+    const double a6[6] = {(double)ach[0], (double)ach[1], (double)ach[2], (double)ach[3], (double)ach[4], (double)ach[5]};
+    const double d = pos_distance(a6, goal);
     double th = 0.0;
     bool succ;
     if (KIND == URGYM_ENV_OBS) {
       succ = d < cfg.distance_threshold;
     } else {
-      double a3[3] = {(double)ach[3], (double)ach[4], (double)ach[5]};
-      th = angular_distance(a3, goal + 3);
+      th = angular_distance(a6 + 3, goal + 3);
       succ = (d < cfg.distance_threshold) && (th < cfg.ori_threshold);
     }
-    int flags = s_flags[pe] & ~(COLL_BIT | EE_BIT);
+    int flags = s_flags[pe] & ~(COLL_BIT | EE_BIT | EPA_MASK);
     if (MODE == MODE_STEP) {
       bool terminated = succ || coll;                 // core.py:313
       bool info_success = terminated ? !coll : false; // core.py:315
@@ -992,6 +1098,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
                 SOA(B.obst_end, i, n, N) = REC(P, sl, REC_END + i, n);
                 SOA(B.obst_vel, i, n, N) = REC(P, sl, REC_VEL + i, n);
               }
+              for (int i = 0; i < 3; i++) SOA(B.obst_vel, 6 + i, n, N) = REC(P, sl, REC_DP + i, n);
               oq2 = Q4{REC(P, sl, REC_QUAT + 0, n), REC(P, sl, REC_QUAT + 1, n), REC(P, sl, REC_QUAT + 2, n), REC(P, sl, REC_QUAT + 3, n)};
               for (int i = 0; i < 3; i++) { op2[i] = st2[i]; SOA(B.obst_pos, i, n, N) = st2[i]; }
               SOA(B.obst_quat, 0, n, N) = oq2.x; SOA(B.obst_quat, 1, n, N) = oq2.y; SOA(B.obst_quat, 2, n, N) = oq2.z; SOA(B.obst_quat, 3, n, N) = oq2.w;
@@ -1030,7 +1137,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
           for (int i = 0; i < 6; i++) { st[i] = SOA(B.obst_start, i, n, N); en[i] = SOA(B.obst_end, i, n, N); }
           dyn_velocity(st, en, cfg.dyn_time_duration, vel);
         }
+        double dp[3];
+        step_displacement(vel, cfg.dt, dp);
         for (int i = 0; i < 6; i++) SOA(B.obst_vel, i, n, N) = vel[i];
+        for (int i = 0; i < 3; i++) SOA(B.obst_vel, 6 + i, n, N) = dp[i];
       }
       if (MODE == MODE_RESET) {
         B.step_count[n] = 0;
@@ -1103,15 +1213,15 @@ __global__ void ee_pose_kernel(const double* q, float* out) {
 __global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, const double* par_a, const double* pose_a,
                                      const int* type_b, const double* par_b, const double* pose_b, double threshold,
                                      double* out_dist, int* out_info) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= count) return;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i0 < count;
+  const int i = live ? i0 : count - 1;  // idle lanes shadow the last query (the wave stays whole for the EPA below)
   auto mk = [](int type, const double* par, double& margin) {
     ShapeDesc s;
     s.type = type; s.hull = 0; s.hx = s.hy = s.hz = 0.0;
-    auto safe = [](double a, double b, double c) { double m = 0.1 * fmin(a, fmin(b, c)); return m < 0.04 ? m : 0.04; };
     if (type == SH_HULL) { s.hull = (int)par[0] - 1; margin = M_HULL; }
-    else if (type == SH_CYLZ) { double m = safe(par[0], par[0], 0.5 * par[1]); s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; margin = m; }
-    else if (type == SH_BOX) { double m = safe(par[0], par[1], par[2]); s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; margin = m; }
+    else if (type == SH_CYLZ) { const double m = M_PRIM; s.hx = s.hy = par[0] - m; s.hz = 0.5 * par[1] - m; margin = m; }
+    else if (type == SH_BOX) { const double m = M_PRIM; s.hx = par[0] - m; s.hy = par[1] - m; s.hz = par[2] - m; margin = m; }
     else { margin = par[0]; }
     return s;
   };
@@ -1126,11 +1236,53 @@ __global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, 
   Tb.t = d3(pb[0], pb[1], pb[2]);
   __shared__ double s_pose[GJK_SLOT_DOUBLES][64];
   const XRef slot{(URGYM_LDS double*)&s_pose[0][0] + threadIdx.x, 64};
-  store(slot, rel(Tb, Ta));
-  int info;
-  const double core = gjk_core_distance(g, A, slot, Bs, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
-  out_dist[i] = (info & GJK_PENETRATING) ? -(ma + mb) : core - ma - mb;
-  out_info[i] = info;
+  int info = 0;
+  double core = 0.0;
+  if (live) {
+    store(slot, rel(Tb, Ta));
+    core = gjk_core_distance(g, A, slot, Bs, rotT(Tb, d3(0, 1, 0)), ma + mb + 0.02 + threshold, info);
+    out_dist[i] = core - ma - mb;
+    out_info[i] = info;
+  }
+  // overlapping cores: penetration depth by the wave-cooperative EPA, query by query
+  unsigned long long pen = __ballot(live && (info & GJK_PENETRATING));
+  const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0], 64};
+#pragma unroll 1
+  while (pen) {
+    const int l = __builtin_ctzll(pen);
+    pen &= pen - 1ull;
+    const int j = blockIdx.x * blockDim.x + l;  // every lane rebuilds the operands of query j
+    double mja, mjb;
+    const ShapeDesc Aj = mk(type_a[j], par_a + 3 * j, mja), Bj = mk(type_b[j], par_b + 3 * j, mjb);
+    X3 Tja, Tjb;
+    const double* qa = pose_a + 7 * j;
+    const double* qb = pose_b + 7 * j;
+    quat_to_rot(Q4{qa[3], qa[4], qa[5], qa[6]}, Tja.r);
+    Tja.t = d3(qa[0], qa[1], qa[2]);
+    quat_to_rot(Q4{qb[3], qb[4], qb[5], qb[6]}, Tjb.r);
+    Tjb.t = d3(qb[0], qb[1], qb[2]);
+    epa_wave_sync();
+    store(XRef{ws.base, ws.stride}, rel(Tjb, Tja));
+    epa_wave_sync();
+    bool capped;
+    const double depth = epa_wave(g, Aj, Bj, ws, (int)threadIdx.x, capped);
+    const int info_l = __shfl(info, l);
+    if ((int)threadIdx.x == l) {  // (the lane that owns query j: its earlier provisional stores are overwritten in order)
+      out_dist[j] = -(depth + mja + mjb);
+      out_info[j] = info_l | (capped ? GJK_ITERCAP : 0);
+    }
+    epa_wave_sync();
+  }
+}
+
+// unit probe: utils.distance / utils.angular_distance through the very device functions P4 calls (tests only)
+__global__ void probe_pose_distance_kernel(int count, const double* a6, const double* b6, double* out2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  double a[6], b[6];
+  for (int k = 0; k < 6; k++) { a[k] = a6[6 * i + k]; b[k] = b6[6 * i + k]; }
+  out2[2 * i + 0] = pos_distance(a, b);
+  out2[2 * i + 1] = angular_distance(a + 3, b + 3);
 }
 
 // compaction of an explicit reset / refresh mask into done_list (mask == nullptr: every env)
@@ -1278,11 +1430,19 @@ void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream
   P.envs = envs;
   if (items < 0) items = h->cfg.num_envs;                       // list-driven launches: an upper bound of the list length
   dim3 grid((unsigned)((items + envs - 1) / envs)), block(THREADS);
+  // which launches can consume a penetration depth: see need_epa in the kernel
+  const bool epa = (MODE != MODE_STEP) || !h->cfg.check_collision;
   switch (h->cfg.env_kind) {
-    case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE>), grid, block, 0, s, P, actions); break;
-    case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE>), grid, block, 0, s, P, actions); break;
-    case URGYM_ENV_STA: hipLaunchKernelGGL((env_kernel<URGYM_ENV_STA, MODE>), grid, block, 0, s, P, actions); break;
-    default: hipLaunchKernelGGL((env_kernel<URGYM_ENV_DYN, MODE>), grid, block, 0, s, P, actions); break;
+    case URGYM_ENV_ORI: hipLaunchKernelGGL((env_kernel<URGYM_ENV_ORI, MODE, false>), grid, block, 0, s, P, actions); break;
+    case URGYM_ENV_OBS: hipLaunchKernelGGL((env_kernel<URGYM_ENV_OBS, MODE, true>), grid, block, 0, s, P, actions); break;
+    case URGYM_ENV_STA:
+      if (epa) hipLaunchKernelGGL((env_kernel<URGYM_ENV_STA, MODE, true>), grid, block, 0, s, P, actions);
+      else hipLaunchKernelGGL((env_kernel<URGYM_ENV_STA, MODE, false>), grid, block, 0, s, P, actions);
+      break;
+    default:
+      if (epa) hipLaunchKernelGGL((env_kernel<URGYM_ENV_DYN, MODE, true>), grid, block, 0, s, P, actions);
+      else hipLaunchKernelGGL((env_kernel<URGYM_ENV_DYN, MODE, false>), grid, block, 0, s, P, actions);
+      break;
   }
 }
 
@@ -1432,6 +1592,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   if (cfg->env_kind < 0 || cfg->env_kind > 3 || cfg->num_envs <= 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad env_kind/num_envs");
   if (cfg->gjk_start != URGYM_GJK_START_BULLET && cfg->gjk_start != URGYM_GJK_START_GUIDED)
     return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad gjk_start");
+  if (cfg->link_dist_scope != URGYM_LINK_DIST_OBSTACLE && cfg->link_dist_scope != URGYM_LINK_DIST_WORKBENCH)
+    return fail(nullptr, URGYM_ERR_ARG, "urgym_create: bad link_dist_scope");
   if (device < 0) return fail(nullptr, URGYM_ERR_ARG, "urgym_create: this library has no CPU path; device must be a HIP ordinal >= 0");
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
@@ -1477,10 +1639,10 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     hipError_t oe = hipSuccess;
     switch (cfg->env_kind) {
-      case URGYM_ENV_ORI: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_ORI, MODE_STEP>, THREADS, 0); break;
-      case URGYM_ENV_OBS: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_OBS, MODE_STEP>, THREADS, 0); break;
-      case URGYM_ENV_STA: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_STA, MODE_STEP>, THREADS, 0); break;
-      default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP>, THREADS, 0); break;
+      case URGYM_ENV_ORI: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_ORI, MODE_STEP, false>, THREADS, 0); break;
+      case URGYM_ENV_OBS: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_OBS, MODE_STEP, true>, THREADS, 0); break;
+      case URGYM_ENV_STA: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_STA, MODE_STEP, false>, THREADS, 0); break;
+      default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP, false>, THREADS, 0); break;
     }
     if (oe != hipSuccess || per_cu < 1) per_cu = 3;
     long slots = (long)cus * per_cu;
@@ -1653,6 +1815,16 @@ int urgym_probe_closest(void* handle, int count, const int* type_a, const double
   return URGYM_OK;
 }
 
+int urgym_probe_pose_distance(void* handle, int count, const double* a6, const double* b6, double* out2, void* stream) {
+  Handle* h = (Handle*)handle;
+  if (!h || count < 0 || (count > 0 && (!a6 || !b6 || !out2))) return fail(h, URGYM_ERR_ARG, "urgym_probe_pose_distance: bad argument");
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (count == 0) return URGYM_OK;
+  hipLaunchKernelGGL(probe_pose_distance_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, count, a6, b6, out2);
+  HIP_TRY(h, hipGetLastError());
+  return URGYM_OK;
+}
+
 int urgym_enable_timing(void* handle, int enable) {
   Handle* h = (Handle*)handle;
   if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
@@ -1685,7 +1857,7 @@ int urgym_query_timing(void* handle, double* step_us, double* reset_us, int* lau
 
 #ifdef URGYM_STAMPS
 int urgym_debug_occupancy(int* blocks_per_cu) {
-  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP>, THREADS, 0);
+  return (int)hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP, false>, THREADS, 0);
 }
 int urgym_debug_stamps(unsigned long long* out, int count) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * (size_t)count, 0, hipMemcpyDeviceToHost);

@@ -135,8 +135,14 @@ class UR5ReachVectorEnv:
         if seed is not None:
             self._seed = int(seed)
             s = C.c_uint64(self._seed)
-        elif self._needs_reset:
+            if mask is None:
+                # Gymnasium seeding contract: reset(seed=s) starts the SAME episodes every time.  The sampler is keyed by
+                # (seed, env, episode id), so a seeded full reset rewinds the episode counters.
+                self.buf["episode_id"].zero_()
+        elif self._needs_reset:  # first reset, or the first one after SB3VecEnvAdapter.seed(): same rule
             s = C.c_uint64(self._seed)
+            if mask is None:
+                self.buf["episode_id"].zero_()
         else:
             s = C.c_uint64(_abi.KEEP_SEED)
         keep, mp = self._mask_ptr(mask)
@@ -159,14 +165,22 @@ class UR5ReachVectorEnv:
         b = self.buf
         # the flag buffers hold 0 / 1 bytes: reinterpret them as bool instead of launching a conversion kernel per flag
         terminated, truncated = b["terminated"].view(torch.bool), b["truncated"].view(torch.bool)
-        info = {"is_success": b["is_success"].view(torch.bool), "collision": b["collision"].view(torch.bool)}
+        # status: the per-env URGYM_STATUS_* word (sticky): penetration depths consumed, joint limits passed, NaN, ... (include/urgym.h)
+        info = {"is_success": b["is_success"].view(torch.bool), "collision": b["collision"].view(torch.bool), "status": b["status"]}
         if self.copy_obs:  # like the observations: private copies on request, zero-copy views of the live buffers otherwise
             terminated, truncated = terminated.clone(), truncated.clone()
             info = {k: v.clone() for k, v in info.items()}
         if self.cfg.auto_reset:
-            info = _LazyInfo(info, {"_final_observation": lambda: terminated | truncated})  # (a kernel launch only if somebody looks)
-            info["final_observation"] = {"observation": b["final_observation"], "achieved_goal": b["final_achieved_goal"],
-                                         "desired_goal": b["final_desired_goal"]}
+            if self.copy_obs:  # private copies: the mask is materialised now, it must not read the flags of a later step
+                info["_final_observation"] = terminated | truncated
+                info["final_observation"] = {"observation": b["final_observation"].clone(), "achieved_goal": b["final_achieved_goal"].clone(),
+                                             "desired_goal": b["final_desired_goal"].clone()}
+            else:
+                # zero-copy mode: like the observations, these are views of live buffers, valid until the next step() / reset();
+                # the mask is derived on first access (a kernel launch only if somebody looks) -- read it before stepping again
+                info = _LazyInfo(info, {"_final_observation": lambda: terminated | truncated})
+                info["final_observation"] = {"observation": b["final_observation"], "achieved_goal": b["final_achieved_goal"],
+                                             "desired_goal": b["final_desired_goal"]}
         reward = b["reward"].clone() if self.copy_obs else b["reward"]
         return self._obs(), reward, terminated, truncated, info
 
@@ -258,6 +272,15 @@ class UR5ReachVectorEnv:
         _native.check(self.lib.urgym_probe_closest(self._h, n, p(ta), p(pa), p(xa), p(tb), p(pb), p(xb), float(threshold), p(out), p(info),
                                                   self._stream()), self._h)
         return out.cpu().numpy(), info.cpu().numpy()
+
+    def probe_pose_distance(self, a6, b6):
+        """Unit probe of the device utils.distance / utils.angular_distance (urgym_probe_pose_distance): [n, 6] poses -> [n, 2]."""
+        a = torch.as_tensor(np.asarray(a6, np.float64).reshape(-1, 6), device=self.device).contiguous()
+        b = torch.as_tensor(np.asarray(b6, np.float64).reshape(-1, 6), device=self.device).contiguous()
+        out = torch.zeros((a.shape[0], 2), dtype=torch.float64, device=self.device)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        _native.check(self.lib.urgym_probe_pose_distance(self._h, a.shape[0], p(a), p(b), p(out), self._stream()), self._h)
+        return out.cpu().numpy()
 
     # ------------------------------------------------------------------------------------------------ timing
     def enable_timing(self, on=True):
