@@ -5,15 +5,19 @@
 
 A "step" is one call of VectorEnv.step() (fused step kernel + device-side auto-reset of finished envs) over one
 batch of synthetic actions for every environment of this rank.  Workload at N=1: BASELINE.json configs[3],
-UR5DynReach-v1 with 65536 environments on one MI355X (the configuration the metric is quoted on).  For N>1 the
-driver launches one rank per GPU through torch.distributed.run; environments shard across ranks with no
-data-path collective (weak scaling: 65536 envs per GPU); the barrier + max-over-ranks timing uses RCCL.
+UR5DynReach-v1 with 65536 environments on one MI355X (the configuration the metric is quoted on).  For N>1 there is
+one rank per GPU: either the driver launches them through torch.distributed.run, or -- when this file is started as
+plain `python bench.py --gpus N` -- it starts that launcher itself as a CHILD process (the parent never touches the GPU)
+and relays rank 0's JSON line and the exit code.  Environments shard across ranks with no data-path collective (weak
+scaling: 65536 envs per GPU); the barrier + max-over-ranks timing uses RCCL; `--gather-obs` adds the one optional
+exchange of the path, an all-gather of the observations (12.3 MB per GPU per step at 65536 envs).
 
 Rank 0 prints ONE JSON line.  `roofline.achieved` prices the dominant kernel (env_kernel<Dyn, STEP>) with the
 algorithmic bytes of SURVEY.md §8(d) (418 B per env-step) against the HBM peak; the kernel's duration is measured
 live with HIP events on the launch stream (urgym_enable_timing).  `cpu_baseline` times the CPU oracle
 (oracle/, kind "port": the reference's PyBullet path cannot run here) on rank 0's host cores over a bounded
-sample of the same workload.
+sample of the same workload, and -- SURVEY.md section 8d "outputs compared at the end of the timed loop" -- steps a slice
+of the GPU's final state once on both sides and reports the largest deviations (`parity_check`).
 """
 import argparse
 import json
@@ -83,6 +87,65 @@ def cpu_baseline(env_id, seed, budget_s=12.0):
             "single_thread_value": n1 * s1 / d1, "single_thread_sample": f"{n1} envs x {s1} steps ({d1:.1f} s)"}
 
 
+
+STATUS_BITS = {1: "nan", 2: "reset_exhausted", 4: "reset_collision", 8: "penetration_depth_consumed", 16: "gjk_or_epa_iteration_cap",
+               32: "joint_limit_passed", 64: "stale_episode_record"}
+
+
+def parity_check(env, actions, m=512):
+    """After the timed loop: the first m envs of the GPU's current state are stepped once more on the GPU and, from the very
+    same state and actions, by the CPU oracle; every output is compared (the checker leg of cpu_baseline, never timed)."""
+    from oracle import binding as ob
+    from ur_gym_amd import _abi
+
+    m = min(m, env.num_envs)
+    state = {k: v[..., :m].copy() for k, v in env.get_state().items()}
+    orc = ob.OracleEnv(env.env_kind, m, threads=min(16, os.cpu_count() or 1), auto_reset=0, check_collision=int(env.cfg.check_collision),
+                       gjk_start=int(env.cfg.gjk_start), link_dist_scope=int(env.cfg.link_dist_scope))
+    orc.load_state(state)
+    orc.buf["observation"][...] = env.buf["observation"][:m].cpu().numpy()  # (carries the stale velocity slot of the Dyn observation)
+    env.step(actions)
+    torch.cuda.synchronize(env.device)
+    orc.step(actions[:m].cpu().numpy())
+    done = (orc.buf["terminated"] | orc.buf["truncated"]).astype(bool)
+    # finished envs were auto-reset on the GPU: their terminal observation is what the oracle (auto-reset off) still shows
+    obs_gpu = env.buf["observation"][:m].cpu().numpy().astype(np.float64)
+    fin_gpu = env.buf["final_observation"][:m].cpu().numpy().astype(np.float64)
+    obs_gpu[done] = fin_gpu[done]
+    d = np.abs(obs_gpu - orc.buf["observation"])
+    euler = [3, 4, 5] + ([21, 22, 23] if env.env_kind in (_abi.ENV_DYN, _abi.ENV_STA) else [])
+    d[:, euler] = np.minimum(d[:, euler], np.abs(d[:, euler] - 2 * np.pi))  # atan2 branch cut at +-pi
+    flags_equal = all(np.array_equal(env.buf[k][:m].cpu().numpy(), orc.buf[k]) for k in ("terminated", "truncated", "is_success", "collision"))
+    out = {"envs": m, "max_abs_dev_observation": float(d.max()),
+           "max_abs_dev_reward": float(np.abs(env.buf["reward"][:m].cpu().numpy().astype(np.float64) - orc.buf["reward"]).max()),
+           "flags_equal": bool(flags_equal), "finished_in_slice": int(done.sum()), "tolerance": 1e-4}
+    orc.close()
+    return out
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 outside a launcher: this process has not touched the GPU (torch is only imported);
+    it starts one rank per GPU through torch.distributed.run as a child, relays rank 0's JSON line and the exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, env=child_env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    for ln in p.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    rc = p.returncode if p.returncode != 0 else (0 if lines else 1)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,9 +166,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        spawn_ranks(args)  # does not return
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: WORLD_SIZE={world} does not match --gpus {args.gpus}")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -134,13 +198,21 @@ def main():
     n_act = min(args.steps + args.warmup, 64)  # distinct action batches, cycled (random policy as demo.py:11)
     actions = torch.rand((n_act, n, 6), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     gathered = None
+    gloo = dist is not None and dist.get_backend() == "gloo"
     if args.gather_obs and world > 1:
-        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device=dev)
+        # the optional exchange of the path: every rank ends up with all observations (RCCL all-gather over xGMI; in the
+        # one-GPU rehearsal gloo gathers through a pinned host staging buffer)
+        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device="cpu" if gloo else dev)
+        stage = torch.empty((n, env.obs_dim), dtype=torch.float32, pin_memory=True) if gloo else None
 
     def one_step(k):
         env.step(actions[k % n_act])
         if gathered is not None:
-            dist.all_gather_into_tensor(gathered, env.buf["observation"])
+            if gloo:
+                stage.copy_(env.buf["observation"])  # (synchronises with the step on the current stream)
+                dist.all_gather(list(gathered.view(world, n, env.obs_dim).unbind(0)), stage)
+            else:
+                dist.all_gather_into_tensor(gathered, env.buf["observation"])
 
     for k in range(args.warmup):
         one_step(k)
@@ -172,6 +244,7 @@ def main():
 
     status = env.buf["status"]
     anomalies = int((status != 0).sum().item())
+    anomaly_bits = {name: int(((status & bit) != 0).sum().item()) for bit, name in STATUS_BITS.items()}
     episodes = int(env.buf["episode_id"].sum().item())
     if rank == 0:
         total_envs = n * world
@@ -205,10 +278,16 @@ def main():
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
                          "note": "bound by the dependent float64 chain of the GJK iterations (resident waves, then VALU issue), not by HBM (DESIGN.md section 4)"},
             "anomalous_envs": anomalies,
+            "anomalous_envs_by_status_bit": anomaly_bits,  # informational bits included (include/urgym.h URGYM_STATUS_*)
             "episodes_started": episodes,
         }
+        if gathered is not None:
+            out["config"]["gather_bytes_per_gpu_per_step"] = n * env.obs_dim * 4
+            ok = bool(torch.equal(gathered.view(world, n, env.obs_dim)[rank].to(dev), env.buf["observation"]))
+            out["config"]["gather_own_shard_intact"] = ok
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
+            out["cpu_baseline"]["parity_check"] = parity_check(env, actions[(args.warmup + args.steps) % n_act])
         print(json.dumps(out), flush=True)
     env.close()
     if dist is not None:

@@ -76,6 +76,9 @@ enum {
   URGYM_STATUS_RESET_COLLISION = 4,  /* "Collision after reset, this should not happen" (reach.py:682-683) */
   URGYM_STATUS_PENETRATION = 8,      /* informational: a link_dist that was consumed is a penetration depth (negative) */
   URGYM_STATUS_GJK_ITER = 16,        /* GJK / EPA hit its iteration cap */
+  URGYM_STATUS_STALE_RECORD = 64,    /* an env finished while the episode counter the caller had edited no longer matched its
+                                        prefetched episode record, and urgym_invalidate_records had not been called: the env was
+                                        NOT reset */
   URGYM_STATUS_JOINT_LIMIT = 32,     /* a joint was commanded past its URDF limit (ur5e.urdf:237-277: elbow +-pi, others +-2pi).
                                         The reference teleports joints with resetJointState, which does not clamp, but Bullet's
                                         limit constraints then act during stepSimulation: from here on the kinematic model of this
@@ -183,6 +186,11 @@ int urgym_rollout(void* handle, const float* actions_dev, int num_steps, void* s
  * overwritten goal / obst_start / obst_end (and possibly q) for the masked envs; this recomputes obstacle pose,
  * velocity, collision, link_dist and the observation for them, leaving step_count untouched. */
 int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream);
+
+/* The caller has edited episode_id (or step_count) of some envs in the bound buffers: the episode records the library keeps ready
+ * for the inline auto-reset may no longer match, so the next max_episode_steps + 1 steps carry the fallback
+ * launches that reset such envs with a kernel.  Not needed after urgym_bind / urgym_reset (they do it themselves); cheap. */
+int urgym_invalidate_records(void* handle);
 
 /* Unit probe of the device closest-distance routine (what p.getClosestPoints computes, pyb_setup.py:401-452): one query per
  * entry, all pointers are DEVICE pointers.  type: 0 hull (par[0] = PyBullet link 1..6), 1 cylinder-Z (radius, height),

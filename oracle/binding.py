@@ -223,6 +223,11 @@ def set_primitive_margin(m):
     lib().urgym_oracle_set_primitive_margin(float(m))
 
 
+def set_collision_groups(bits):
+    """What-if (ablation tool only): bit 0 obstacle, bit 1 table + track, bit 2 self pairs; 7 = the reference."""
+    lib().urgym_oracle_set_collision_groups(int(bits))
+
+
 def last_epa_iterations():
     return lib().urgym_oracle_last_epa_iterations()
 

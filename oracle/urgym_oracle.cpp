@@ -749,23 +749,26 @@ void link_distances(const X3 link[7], const Shape& obstacle, double out[5], int*
     }
   }
 }
+// What-if switch (tools/closed_loop_ablation.py only): which groups of pairs check_collision tests -- bit 0 obstacle,
+// bit 1 table + track, bit 2 self pairs.  7 = the reference.
+int g_collision_groups = 7;
 // PyBullet.check_collision (pyb_setup.py:382-429). has_obstacle mirrors `keys[5] == 'obstacle'` (398-399).
 bool check_collision(const X3 link[7], bool has_obstacle, const Shape* obstacle, double margin, int gjk_start) {
   const bool guided = gjk_start == URGYM_GJK_START_GUIDED;
   V3 ax;
-  if (has_obstacle)
+  if (has_obstacle && (g_collision_groups & 1))
     for (int l = 2; l <= 6; l++) {
       ax = guided_axis(l, link[l], obstacle->pose.t);
       if (gjk_distance(make_hull(l, link[l]), *obstacle, margin, guided ? &ax : nullptr).has_point) return true;
     }
   Shape objs[2] = {scene_table(), scene_track()};
-  for (int o = 0; o < 2; o++)
+  for (int o = 0; o < 2 && (g_collision_groups & 2); o++)
     for (int l = 2; l <= 6; l++) {
       ax = guided_axis(l, link[l], objs[o].pose.t);
       if (gjk_distance(make_hull(l, link[l]), objs[o], margin, guided ? &ax : nullptr).has_point) return true;
     }
   int start = 3;
-  for (int la = 1; la < 4; la++) {
+  for (int la = 1; la < 4 && (g_collision_groups & 4); la++) {
     for (int lb = start; lb < 7; lb++) {
       ax = guided_axis(la, link[la], capsule_mid(lb, link[lb]));
       if (gjk_distance(make_hull(la, link[la]), make_hull(lb, link[lb]), margin, guided ? &ax : nullptr).has_point) return true;
@@ -1397,6 +1400,7 @@ int urgym_oracle_query(const double* q, const double* obst_pose, int has_obstacl
   return status;
 }
 void urgym_oracle_set_emulation(int flags) { g_emulate = flags; }
+void urgym_oracle_set_collision_groups(int bits) { g_collision_groups = bits; }
 int urgym_oracle_last_epa_iterations(void) { return g_last_epa_iterations; }
 void urgym_oracle_set_primitive_margin(double m) { g_prim_margin_override = m; }
 void urgym_oracle_philox(uint64_t seed, uint32_t env, uint32_t episode, uint32_t attempt, double* u20) {

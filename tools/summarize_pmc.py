@@ -8,7 +8,7 @@ for f in glob.glob(f"{d}/*/*/*counter_collection.csv"):
     df = pd.read_csv(f)
     df = df[df.Kernel_Name.str.contains("env_kernel")]
     if df.empty: continue
-    df["kernel"] = df.Kernel_Name.str.extract(r"(env_kernel<\d, \d>)")
+    df["kernel"] = df.Kernel_Name.str.extract(r"(env_kernel<\d, \d)")[0] + ">"  # key: env_kernel<KIND, MODE> (the EPA flag is dropped)
     g = df.groupby(["kernel", "Counter_Name"]).Counter_Value.mean().unstack()
     for k, row in g.iterrows():
         out.setdefault(k, {}).update({c: float(v) for c, v in row.items()})
@@ -18,6 +18,12 @@ for f in glob.glob(f"{d}/*/*/*counter_collection.csv"):
 for k, v in out.items():
     if "SQ_THREAD_CYCLES_VALU" in v: v["valu_lane_utilisation"] = v["SQ_THREAD_CYCLES_VALU"] / (v["SQ_ACTIVE_INST_VALU"] * 64)
     if "SQ_WAIT_ANY" in v: v["wait_fraction_of_wave_cycles"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    if "SQ_BUSY_CYCLES" in v and "SQ_ACTIVE_INST_VALU" in v:
+        # VALU-issue roofline: SQ_ACTIVE_INST_* count quad-cycles (MI355X_MICROARCH.md), SQ_BUSY_CYCLES is summed over the 32 shader
+        # engines (8 XCDs x 4) -> kernel duration in shader cycles = SQ_BUSY_CYCLES / 32; 256 CUs x 4 SIMDs can each issue one VALU cycle per cycle
+        v["kernel_shader_cycles"] = v["SQ_BUSY_CYCLES"] / 32.0
+        v["valu_busy_fraction_of_simd_cycles"] = 4.0 * v["SQ_ACTIVE_INST_VALU"] / (1024.0 * v["kernel_shader_cycles"])
+        v["wave_slot_occupancy"] = 4.0 * v["SQ_WAVE_CYCLES"] / (256.0 * 12.0 * v["kernel_shader_cycles"]) if v.get("LDS_Block_Size", 0) else None
     if "FETCH_SIZE" in v: v["hbm_read_bytes_per_launch_corrected"] = v["FETCH_SIZE"] * 1024 * 2  # gfx950: FETCH_SIZE = 1/2 of wide reads (MI355X_MICROARCH.md)
     if "WRITE_SIZE" in v: v["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in v: v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
@@ -26,6 +32,6 @@ for f in glob.glob(f"{d}/trace/*/*kernel_stats.csv"):
     ks = ks[ks.Name.str.contains("env_kernel")]
     for _, r in ks.iterrows():
         import re
-        k = re.search(r"(env_kernel<\d, \d>)", r.Name).group(1)
+        k = re.search(r"(env_kernel<\d, \d)", r.Name).group(1) + ">"
         out.setdefault(k, {}).update({"calls": int(r.Calls), "avg_ns": float(r.AverageNs), "min_ns": float(r.MinNs), "max_ns": float(r.MaxNs)})
 print(json.dumps(out, indent=1))

@@ -14,6 +14,7 @@ STATUS_RESET_COLLISION = 4
 STATUS_PENETRATION = 8
 STATUS_GJK_ITER = 16
 STATUS_JOINT_LIMIT = 32
+STATUS_STALE_RECORD = 64
 
 OBS_DIMS = {ENV_ORI: (18, 6), ENV_OBS: (26, 3), ENV_DYN: (35, 6), ENV_STA: (29, 6)}  # (observation, goal) — core.py:241-247
 
@@ -101,6 +102,7 @@ EXPORTED_SYMBOLS = [
     "urgym_step",
     "urgym_rollout",
     "urgym_refresh",
+    "urgym_invalidate_records",
     "urgym_probe_closest",
     "urgym_probe_pose_distance",
     "urgym_enable_timing",

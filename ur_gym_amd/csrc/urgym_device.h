@@ -377,17 +377,15 @@ __device__ __forceinline__ void stw(XRef T, int i, D3 w) { T.set(12 + 3 * i, w.x
 struct GjkRun {
   D3 v;             // Bullet's m_cachedSeparatingAxis
   double sq;        // squaredDistance
-  double max_d2;
   int n;            // simplex size (vertices in the LDS slot)
   int iter;
   int info;         // GJK_* flags, valid when done
   double core;      // result (core distance), valid when done
   bool done;
 };
-__device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0, double max_d) {
+__device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0) {
   r.v = v0;
   r.sq = 1.0e300;
-  r.max_d2 = max_d * max_d;
   r.n = 0;
   r.iter = 0;
   r.info = 0;
@@ -407,8 +405,9 @@ __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int de
   if (degenerate == 10) r.info |= GJK_SEPARATED;
   r.core = sqrt(l2);
 }
-// one iteration of btGjkPairDetector's loop
-__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B) {
+// one iteration of btGjkPairDetector's loop.  max_d: Bullet's early-out distance of this query (handed in per call rather than
+// kept in the run: callers derive it from the query's kind, which costs less than two VGPRs across the loop)
+__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
   D3 w;
@@ -418,7 +417,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     w = p - q;
   }
   const double delta = dot(r.v, w);
-  if (delta > 0.0 && delta * delta > r.sq * r.max_d2) { gjk_finish(r, true, 10); return; }
+  if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { gjk_finish(r, true, 10); return; }
   {
     bool in = false;
     for (int i = 0; i < r.n; i++) in = in || (len2(ldw(T, i) - w) <= 1e-12);
@@ -721,8 +720,8 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
 __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
                                                     D3 v0, double max_d, int& info) {
   GjkRun r;
-  gjk_begin(r, v0, max_d);
-  while (!r.done) gjk_iterate(r, g, A, T, B);
+  gjk_begin(r, v0);
+  while (!r.done) gjk_iterate(r, g, A, T, B, max_d);
   info = r.info;
   return r.core;
 }

@@ -107,6 +107,8 @@ struct KParams {
   int* rcount;      // number of entries in rlist
   int rcap;         // capacity of rlist
   int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
+  int* rzero2;      // a second one
+  int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
   int prefetch;     // 1: STEP resets finished envs inline from valid records; RESET files refill entries
   float neutral_ach[6];  // end-effector position + Euler angles of the neutral pose, float32 as _get_obs casts them (set at create)
 };
@@ -528,7 +530,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int OD = P.obs_dim, GD = P.goal_dim;
+  // observation / goal widths (core.py:241-247): compile-time per env kind, so that the row loops unroll and no per-lane
+  // array is indexed dynamically (that would live in scratch)
+  constexpr int OD = (KIND == URGYM_ENV_ORI) ? 18 : ((KIND == URGYM_ENV_OBS) ? 26 : ((KIND == URGYM_ENV_STA) ? 29 : 35));
+  constexpr int GD = (KIND == URGYM_ENV_OBS) ? 3 : 6;
   const int E = P.envs;                      // envs of this workgroup, 1 .. MAX_ENVS
   const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
@@ -544,7 +549,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
   static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
 
-  if (blockIdx.x == 0 && tid == 0 && P.rzero) *P.rzero = 0;  // (before any early exit)
+  if (blockIdx.x == 0 && tid == 0) {  // (before any early exit)
+    if (P.rzero) *P.rzero = 0;
+    if (P.rzero2) *P.rzero2 = 0;
+  }
   int list_count = 0;
   if (MODE != MODE_STEP) {
     list_count = (MODE == MODE_PREFETCH) ? min(*P.rcount, P.rcap) : B.done_count[P.pp];
@@ -687,9 +695,22 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   //             tickets are gone.
   //   A lane advances its query by one GJK iteration per loop trip; a finished lane draws the next item.
   {
-    ShapeDesc sa = hull_desc(1), sb = cyl_desc();
+    // The operands of a lane's query are carried as (kind, la, lb) only; the shape descriptors are re-derived from them at
+    // each use (a handful of selects) instead of living in 16 VGPRs across the loop, which is what used to push the sincos
+    // constants of the set-up into scratch.
     D3 v0 = d3(0, 1, 0);
-    int kind = 3, e = 0, lb = 2;
+    int kind = 3, e = 0, lb = 2, la = 1;
+    auto shape_a = [&]() -> ShapeDesc { return hull_desc(kind == Q_SELF ? la : lb); };
+    auto shape_b = [&]() -> ShapeDesc {
+      ShapeDesc s;
+      s.type = (kind == 3) ? SH_CYLZ : ((kind == Q_SELF) ? SH_HULL : SH_BOX);
+      s.hull = lb - 1;
+      const bool tbl = (kind == Q_TABLE);
+      s.hx = (kind == 3) ? (CYL_R - M_CYL) : (tbl ? (TABLE_HX - M_TABLE) : (TRACK_HX - M_TRACK));
+      s.hy = (kind == 3) ? (CYL_R - M_CYL) : (tbl ? (TABLE_HY - M_TABLE) : (TRACK_HY - M_TRACK));
+      s.hz = (kind == 3) ? (0.5 * CYL_H - M_CYL) : (tbl ? (TABLE_HZ - M_TABLE) : (TRACK_HZ - M_TRACK));
+      return s;
+    };
     bool exact = false;  // table / track item that wants the distance itself (WORKBENCH link_dist), not just "closer than the margin?"
     // URGYM_GJK_START_GUIDED (include/urgym.h): first separating axis = unit vector from the other shape's centre to
     // the mid point of the link's bounding capsule; same arithmetic as the oracle's guided_axis()
@@ -709,7 +730,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       kind = (item >> 8) & 3;
       exact = ((item >> 16) & 1) != 0;
       lb = (item >> 10) & 7;
-      const int la = (item >> 13) & 7;
+      la = (item >> 13) & 7;
       const int n = s_env[e];
       if (n < 0) return false;
       if (MODE == MODE_STEP) {  // P1 may not have judged this env yet: non-finite joints -> no query (same rule as P1)
@@ -737,19 +758,13 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
           quat_to_rot(oqs, To.r);
           To.t = d3(op[0], op[1], op[2]);
         }
-        sa = hull_desc(lb);
-        sb = cyl_desc();
         store(pose_slot, rel(To, T));
         v0 = rotT(To, guided ? guided_axis(capsule_mid(lb, T), To.t) : d3(0, 1, 0));  // Bullet: the world +Y axis
       } else if (kind == Q_SELF) {
-        sa = hull_desc(la);
-        sb = hull_desc(lb);
         store(pose_slot, rel(T, TA));
         v0 = rotT(T, guided ? guided_axis(capsule_mid(la, TA), capsule_mid(lb, T)) : d3(0, 1, 0));
       } else {
         const bool tbl = (kind == Q_TABLE);
-        sa = hull_desc(lb);
-        sb = tbl ? box_desc(TABLE_HX, TABLE_HY, TABLE_HZ, M_TABLE) : box_desc(TRACK_HX, TRACK_HY, TRACK_HZ, M_TRACK);
         const D3 centre = d3(tbl ? TABLE_CX : TRACK_CX, tbl ? TABLE_CY : TRACK_CY, tbl ? TABLE_CZ : TRACK_CZ);
         v0 = guided ? guided_axis(capsule_mid(lb, T), centre) : d3(0, 1, 0);
         T.t = T.t - centre;
@@ -798,14 +813,14 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     STAMP_TIME(2);
     if (tid < n_tickets) {
       busy = setup(ticket_item(tid));
-      if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + 5.0);
+      if (busy) gjk_begin(run, v0);
     }
     STAMP_TIME(3);
     int trips = 0, draws = 0;
     for (;;) {
       trips++;
       if (busy) {
-        gjk_iterate(run, P.graph, sa, pose_slot, sb);
+        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
         if (run.done) {
           const double msum = margin_sum();
           if (kind == 3 || exact) {
@@ -844,7 +859,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         }
         if (item != NO_ITEM) {
           busy = setup(item);
-          if (busy) gjk_begin(run, v0, margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
+          if (busy) gjk_begin(run, v0);
         }
       }
       // nothing left for this wave to draw (STEP: and the pair masks have been published)
@@ -878,7 +893,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
             if (!setup(item)) continue;
             epa_wave_sync();
             bool capped;
-            const double depth = epa_wave(P.graph, sa, sb, ws, lane, capped);
+            const double depth = epa_wave(P.graph, shape_a(), shape_b(), ws, lane, capped);
             if (lane == 0) {
               const double dist = -(depth + margin_sum());
               if (workbench) atomicMin(reinterpret_cast<long long*>(&s_dist[lb - 2][e]), sortable(dist));
@@ -1123,6 +1138,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         if (!consumed) {
           int slot = atomicAdd(&B.done_count[P.pp], 1);
           B.done_list[slot] = n;
+          // no fallback launch follows (the host believed every record valid): the env stays un-reset and says so
+          if (P.prefetch && !P.fallback_on) atomicOr(&B.status[n], URGYM_STATUS_STALE_RECORD);
         }
       }
     } else {
@@ -1324,8 +1341,8 @@ struct Handle {
   float neutral_ach[6] = {0, 0, 0, 0, 0, 0};
   double* d_rec = nullptr;      // [2][REC_FIELDS][N]
   int32_t* d_reci = nullptr;    // [2][2][N]
-  int2* d_rl[3] = {nullptr, nullptr, nullptr};  // refill lists: two alternating asynchronous ones, one synchronous
-  int rl_cap[3] = {0, 0, 0};
+  int2* d_rl[4] = {nullptr, nullptr, nullptr, nullptr};  // refill lists: three rotating asynchronous ones, one synchronous (index 3)
+  int rl_cap[4] = {0, 0, 0, 0};
   int* d_rcount = nullptr;      // their counters
   hipStream_t rs = nullptr;     // side stream of the asynchronous refills
   hipEvent_t ev_step = nullptr, ev_refill = nullptr;
@@ -1333,6 +1350,10 @@ struct Handle {
   int parity = 0;
   uint64_t rec_seed = 0;
   bool rec_seed_valid = false;
+  // Steps left in which a finished env may still meet a record that is not valid for its episode (after create / bind /
+  // urgym_invalidate_records / a reset that did not cover every env): only then does a step carry the fallback launches.
+  // An env that falls back gets fresh records for its next two episodes, and every env finishes within max_episode_steps.
+  int dirty_steps = 0;
 };
 thread_local char g_err[512] = {0};
 
@@ -1418,6 +1439,8 @@ KParams make_params(Handle* h, int copy_final) {
   P.rcount = nullptr;
   P.rcap = 0;
   P.rzero = nullptr;
+  P.rzero2 = nullptr;
+  P.fallback_on = 1;
   P.prefetch = 0;
   for (int i = 0; i < 6; i++) P.neutral_ach[i] = h->neutral_ach[i];
   return P;
@@ -1478,12 +1501,12 @@ void release_prefetch(Handle* h) {
   if (h->ev_refill) { hipEventDestroy(h->ev_refill); h->ev_refill = nullptr; }
   if (h->d_rec) { hipFree(h->d_rec); h->d_rec = nullptr; }
   if (h->d_reci) { hipFree(h->d_reci); h->d_reci = nullptr; }
-  for (int i = 0; i < 3; i++)
+  for (int i = 0; i < 4; i++)
     if (h->d_rl[i]) { hipFree(h->d_rl[i]); h->d_rl[i] = nullptr; }
   if (h->d_rcount) { hipFree(h->d_rcount); h->d_rcount = nullptr; }
 }
 
-// list `which` (0 / 1: asynchronous, 2: synchronous) as the refill list of a launch
+// list `which` (0 .. 2: asynchronous, 3: synchronous) as the refill list of a launch
 void use_list(Handle* h, KParams& P, int which) {
   P.rlist = h->d_rl[which];
   P.rcount = h->d_rcount + which;
@@ -1494,10 +1517,17 @@ void use_list(Handle* h, KParams& P, int which) {
 int do_step(Handle* h, const float* actions, hipStream_t s) {
   KParams P = make_params(h, 1);
   const bool pf = h->prefetch && h->cfg.auto_reset;
-  const int par = h->parity;
+  // Three asynchronous refill lists rotate: step t appends the record slots it consumed to list t % 3 and refill t (side
+  // stream, under step t + 1) reads it.  List (t + 1) % 3 was last read by refill t - 2, which is complete when step kernel t
+  // runs (this stream waited for it during step t - 1, below), so step kernel t itself arms that counter for step t + 1:
+  // no launch and no memset is needed just to recycle a list.
+  const int cur = h->parity, nxt = (cur + 1) % 3;
+  const bool dirty = pf && h->dirty_steps > 0;
   if (pf) {
-    use_list(h, P, par);            // (its counter was armed by the previous step's fallback launch, see below)
-    P.rzero = h->d_rcount + 2;      // the step kernel arms the synchronous list for this step's fallback launch
+    use_list(h, P, cur);
+    P.rzero = h->d_rcount + nxt;
+    P.rzero2 = dirty ? h->d_rcount + 3 : nullptr;  // the synchronous list of this step's fallback launches
+    P.fallback_on = dirty ? 1 : 0;
   }
   int slot = time_begin(h, 0, s);
   launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
@@ -1508,32 +1538,37 @@ int do_step(Handle* h, const float* actions, hipStream_t s) {
     time_end(h, slot, s);
   }
   if (pf) {
-    // Finished envs were reset inline from their prefetched records.  What is left on this stream is the fallback for envs
-    // whose record was not valid (first use, set_state, a refill that did not fit): normally two empty launches.  The
-    // refill of the PREVIOUS step ran under this step's kernel; it must be complete before any record is rewritten here and
-    // before its list is reused by the next step.
+    // Finished envs were reset inline from their prefetched records.  In steady state every record is valid (an env's two slots
+    // hold its next two episodes, and a consumed slot is refilled before the env can need it again), so nothing else has to run
+    // on this stream.  Only while records may be stale (h->dirty_steps > 0: first use, a new binding, urgym_invalidate_records)
+    // does the step carry the fallback: the RESET kernel for envs that found no valid record, then PREFETCH for their next two
+    // episodes -- unbounded, so that an env that fell back comes out clean.
+    // The refill of the PREVIOUS step ran under this step's kernel; it must be complete before a record is rewritten by the
+    // fallback, before the next step kernel can need a record it wrote, and before that kernel re-arms its list.
     if (h->refill_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_refill, 0));
-    slot = time_begin(h, 1, s);
-    KParams Pr = P;
-    use_list(h, Pr, 2);
-    Pr.rzero = h->d_rcount + (par ^ 1);  // the refill that read the other asynchronous list is complete: arm it for the next step
-    launch_mode<MODE_RESET>(h, Pr, nullptr, GROUP, s);
-    Pr.rzero = nullptr;
-    launch_mode<MODE_PREFETCH>(h, Pr, nullptr, 8, s, 4096);   // bounded: entries beyond it stay stale and fall back again
-    time_end(h, slot, s);
+    if (dirty) {
+      slot = time_begin(h, 1, s);
+      KParams Pr = P;
+      use_list(h, Pr, 3);
+      Pr.rzero = Pr.rzero2 = nullptr;
+      launch_mode<MODE_RESET>(h, Pr, nullptr, GROUP, s);
+      launch_mode<MODE_PREFETCH>(h, Pr, nullptr, 8, s, h->rl_cap[3]);
+      time_end(h, slot, s);
+      h->dirty_steps--;
+    }
     // the refill of the slots consumed in this step runs on the side stream, under the next step's kernel
     HIP_TRY(h, hipEventRecord(h->ev_step, s));
     HIP_TRY(h, hipStreamWaitEvent(h->rs, h->ev_step, 0));
     KParams Pa = P;
-    use_list(h, Pa, par);
-    Pa.rzero = nullptr;
+    use_list(h, Pa, cur);
+    Pa.rzero = Pa.rzero2 = nullptr;
     slot = time_begin(h, 2, h->rs);
     // few, dense workgroups: this launch has a whole step to finish, what matters is that it leaves the CUs to the step kernel
-    launch_mode<MODE_PREFETCH>(h, Pa, nullptr, PREFETCH_MAX_ENVS, h->rs, h->rl_cap[par]);
+    launch_mode<MODE_PREFETCH>(h, Pa, nullptr, PREFETCH_MAX_ENVS, h->rs, h->rl_cap[cur]);
     time_end(h, slot, h->rs);
     HIP_TRY(h, hipEventRecord(h->ev_refill, h->rs));
     h->refill_pending = true;
-    h->parity ^= 1;
+    h->parity = nxt;
   }
   h->pp ^= 1;
   HIP_TRY(h, hipGetLastError());
@@ -1553,12 +1588,16 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
         HIP_TRY(h, hipMemsetAsync(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)N, s));
         h->rec_seed = h->seed;
         h->rec_seed_valid = true;
+        h->dirty_steps = h->cfg.max_episode_steps + 1;
       }
-      HIP_TRY(h, hipMemsetAsync(h->d_rcount, 0, 4 * sizeof(int), s));  // (nothing is in flight here)
-      use_list(h, P, 2);
+      HIP_TRY(h, hipMemsetAsync(h->d_rcount, 0, 5 * sizeof(int), s));  // (nothing is in flight here)
+      use_list(h, P, 3);
     }
     launch_mode<MODE_RESET>(h, P, nullptr, GROUP, s);
-    if (pf) launch_mode<MODE_PREFETCH>(h, P, nullptr, 8, s, h->rl_cap[2]);  // the next two episodes of every env just reset
+    if (pf) {
+      launch_mode<MODE_PREFETCH>(h, P, nullptr, 8, s, h->rl_cap[3]);  // the next two episodes of every env just reset
+      if (mask == nullptr) h->dirty_steps = 0;                          // every env now has valid records
+    }
   } else {
     launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP, s);
   }
@@ -1681,14 +1720,15 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     h->prefetch = want_prefetch;
     if (h->prefetch) {
       const size_t nn = (size_t)n;
-      h->rl_cap[0] = h->rl_cap[1] = (int)n;   // at most one entry per env and step: no entry is ever dropped
-      h->rl_cap[2] = (int)(2 * n);
+      h->rl_cap[0] = h->rl_cap[1] = h->rl_cap[2] = (int)n;   // at most one entry per env and step: no entry is ever dropped
+      h->rl_cap[3] = (int)(2 * n);
+      h->dirty_steps = cfg->max_episode_steps + 1;             // no record exists yet
       hipError_t pe = hipMalloc((void**)&h->d_rec, sizeof(double) * 2 * REC_FIELDS * nn);
       if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_reci, sizeof(int32_t) * 4 * nn);
-      for (int i = 0; i < 3 && pe == hipSuccess; i++) pe = hipMalloc((void**)&h->d_rl[i], sizeof(int2) * (size_t)h->rl_cap[i]);
-      if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 4);
+      for (int i = 0; i < 4 && pe == hipSuccess; i++) pe = hipMalloc((void**)&h->d_rl[i], sizeof(int2) * (size_t)h->rl_cap[i]);
+      if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 5);
       if (pe == hipSuccess) pe = hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * nn);
-      if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 4);
+      if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 5);
       if (pe == hipSuccess) {  // the neutral pose's end-effector frame, by the device code itself
         double* dq = nullptr;
         float* dout = nullptr;
@@ -1756,6 +1796,7 @@ int urgym_bind(void* handle, const urgym_buffers* b) {
     HIP_TRY(h, hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)h->cfg.num_envs));
     h->refill_pending = false;
     h->rec_seed_valid = false;
+    h->dirty_steps = h->cfg.max_episode_steps + 1;
   }
   h->buf = *b;
   h->bound = true;
@@ -1769,6 +1810,13 @@ int urgym_reset(void* handle, const uint8_t* mask_dev, uint64_t seed, void* stre
   HIP_TRY(h, hipSetDevice(h->device));
   if (seed != UINT64_MAX) h->seed = seed;
   return do_masked(h, mask_dev, MODE_RESET, (hipStream_t)stream);
+}
+
+int urgym_invalidate_records(void* handle) {
+  Handle* h = (Handle*)handle;
+  if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
+  h->dirty_steps = h->cfg.max_episode_steps + 1;
+  return URGYM_OK;
 }
 
 int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream) {

@@ -252,6 +252,9 @@ class UR5ReachVectorEnv:
         for k, v in state.items():
             t = torch.as_tensor(np.asarray(v), device=self.device).reshape(self.buf[k].shape)
             self.buf[k].copy_(t.to(self.buf[k].dtype))
+        if "episode_id" in state or "step_count" in state:
+            # the library keeps the next episodes of every env prefetched, keyed by episode id: tell it they may no longer match
+            _native.check(self.lib.urgym_invalidate_records(self._h), self._h)
         if refresh:
             self._refresh(None)
         self._needs_reset = False
