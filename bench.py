@@ -33,19 +33,25 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418, "UR5StaReach-v1": 370}  # SURVEY.md §8(d); Sta = Dyn without the velocity slots
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1_final", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command (tools/gpu_round.sh prof)
 
 
-def measured_traffic(env_id, n):
-    """HBM bytes per launch of the step kernel from the committed rocprofv3 PMC summary (FETCH_SIZE corrected x2 as the
-    gfx950 guide prescribes + WRITE_SIZE); only valid for the configuration that was profiled (Dyn, N=65536)."""
+def profiled_counters(env_id, n):
+    """Counters of the step kernel from the committed rocprofv3 PMC summary; only valid for the configuration that was
+    profiled (Dyn, N=65536).  traffic = HBM bytes per launch (FETCH_SIZE corrected x2 as the gfx950 guide prescribes + WRITE_SIZE);
+    valu_* = the VALU-issue picture of the same launches (SQ_ACTIVE_INST_VALU in quad-cycles over the SIMD-cycles of the kernel)."""
     if env_id != "UR5DynReach-v1" or n != 65536 or not os.path.exists(PMC_SUMMARY):
-        return None
+        return None, None
     try:
         k = json.load(open(PMC_SUMMARY))["env_kernel<2, 0>"]
-        return float(k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"])
+        traffic = float(k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"])
+        valu = {"busy_fraction_of_simd_cycles": k.get("valu_busy_fraction_of_simd_cycles"), "lane_utilisation": k.get("valu_lane_utilisation"),
+                "wave_slot_occupancy": k.get("wave_slot_occupancy"), "wait_fraction_of_wave_cycles": k.get("wait_fraction_of_wave_cycles"),
+                "valu_wave_instructions_per_launch": k.get("SQ_INSTS_VALU"), "scratch_bytes_per_lane": k.get("Scratch_Size"),
+                "source": "profiles/r2/pmc_summary.json (static: separate rocprofv3 --pmc passes of this command, not measured in this run)"}
+        return traffic, valu
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(env_id, seed, budget_s=12.0):
@@ -250,6 +256,7 @@ def main():
         total_envs = n * world
         value = total_envs * args.steps / elapsed
         algo = ALGO_BYTES[args.env] * n  # bytes one launch of the step kernel has to move, per rank
+        traffic, valu = profiled_counters(args.env, n)
         achieved = algo / (step_us * 1e-6) / 1e9 if step_us > 0 else 0.0
         out = {
             "metric": "env-steps/sec (whole node)",
@@ -269,8 +276,9 @@ def main():
                        "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout),
                        "gjk_start": args.gjk_start},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.env, n),
-                         "traffic_source": "profiles/r1_final/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": "profiles/r2/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
+                         "valu_issue": valu,  # what really bounds the kernel: float64 VALU issue + the latency of the GJK chains
                          "algorithmic_bytes_per_launch": algo,
                          "kernel": "env_kernel<Dyn,STEP>" if args.env == "UR5DynReach-v1" else "env_kernel<STEP>",
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
