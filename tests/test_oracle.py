@@ -441,3 +441,70 @@ def test_guided_gjk_start_stays_within_path_tolerance(oracle):
     assert worst < 5e-4, worst
     assert over6 < 0.03 * 5 * n and over5 < 0.005 * 5 * n, (over6, over5)
     assert flips <= 3, flips
+
+
+# ------------------------------------------------------------------------------------------------ penetration depth (EPA)
+def test_penetration_depth_analytic_cases(oracle):
+    """Overlapping cores: the oracle reports -(depth of the margin-inflated shapes) like p.getClosestPoints' contact distance
+    (pyb_setup.py:452 stores it): depth(inflated) = depth(cores) + margin_A + margin_B."""
+    cyl = [0.05, 0.4]
+    at = lambda x, y, z: [x, y, z, *IDENT]
+    # sphere r 0.02 inside the obstacle cylinder (r 0.05, h 0.4), 3 cm off the axis: nearest exit is radial, 2 cm + the sphere
+    r = oracle.closest(oracle.SPHERE, [0.02], at(0.03, 0, 0), oracle.CYLZ, cyl, at(0, 0, 0))
+    assert r["penetrating"] and abs(r["distance"] - (-(0.02 + 0.02))) < 1e-8
+    # ... and 1 cm below the top cap on the axis: nearest exit is axial
+    r = oracle.closest(oracle.SPHERE, [0.02], at(0, 0, 0.19), oracle.CYLZ, cyl, at(0, 0, 0))
+    assert r["penetrating"] and abs(r["distance"] - (-(0.01 + 0.02))) < 1e-8
+    # two boxes of half 0.1 overlapping by 5 cm along x (face contact): depth 0.05
+    r = oracle.closest(oracle.BOX, [0.1] * 3, at(0, 0, 0), oracle.BOX, [0.1] * 3, at(0.15, 0.02, 0.01))
+    assert r["penetrating"] and abs(r["distance"] - (-0.05)) < 1e-8
+    # a 5 cm cube sunk 3 cm (centre) below the table top (z = -0.12): it has to rise by 0.05 + 0.03
+    r = oracle.closest(oracle.BOX, [0.05] * 3, at(0.5, 0, -0.15), oracle.BOX, [0.55, 0.9, 0.46], at(0.5, 0, -0.58))
+    assert r["penetrating"] and abs(r["distance"] - (-0.08)) < 1e-8
+    # rigid-motion invariance of a hull <-> cylinder depth
+    rng = np.random.default_rng(3)
+    pa = np.r_[0.4, 0.1, 0.3, Rot.random(random_state=1).as_quat()]
+    pb = np.r_[0.41, 0.12, 0.33, Rot.random(random_state=2).as_quat()]
+    d0 = oracle.closest(oracle.HULL, [3], pa, oracle.CYLZ, cyl, pb)
+    assert d0["penetrating"] and d0["distance"] < -0.002
+    G = Rot.random(random_state=5)
+    t = rng.uniform(-1, 1, 3)
+    mv = lambda p: np.r_[G.apply(p[:3]) + t, (G * Rot.from_quat(p[3:])).as_quat()]
+    d1 = oracle.closest(oracle.HULL, [3], mv(pa), oracle.CYLZ, cyl, mv(pb))
+    assert d1["penetrating"] and abs(d1["distance"] - d0["distance"]) < 1e-7
+
+
+def test_penetration_depth_is_a_lower_envelope_of_the_support_function(oracle):
+    """depth(cores) = min over unit n of h_{A-B}(n): no sampled direction may give a smaller value than the EPA result, and a
+    local search started at the best sample must not get below it either (hull <-> cylinder, the pair of get_link_distances)."""
+    verts = [MODEL["hull_verts"][MODEL["hull_offset"][l - 1]:MODEL["hull_offset"][l]] for l in range(1, 7)]
+    rng = np.random.default_rng(8)
+    checked = 0
+    for _ in range(40):
+        link = int(rng.integers(2, 7))
+        Ra = Rot.random(random_state=int(rng.integers(1 << 30)))
+        ta = rng.uniform(-0.2, 0.2, 3)
+        Rb = Rot.random(random_state=int(rng.integers(1 << 30)))
+        tb = ta + Ra.apply(verts[link - 1].mean(0)) + rng.normal(0, 0.02, 3)
+        got = oracle.closest(oracle.HULL, [link], np.r_[ta, Ra.as_quat()], oracle.CYLZ, [0.05, 0.4], np.r_[tb, Rb.as_quat()])
+        if not got["penetrating"]:
+            continue
+        depth = -got["distance"] - 0.002  # cores
+        Vw = Ra.apply(verts[link - 1]) + ta
+
+        def h(n):  # support of core_A - core_B in direction n (world frame)
+            n = n / np.linalg.norm(n)
+            nb = Rb.inv().apply(-n)
+            s = np.hypot(nb[0], nb[1])
+            pb = np.array([0.049 * nb[0] / s, 0.049 * nb[1] / s, 0.199 * np.sign(nb[2])]) if s > 0 else np.array([0.049, 0, 0.199 * np.sign(nb[2])])
+            return (Vw @ n).max() - (Rb.apply(pb) + tb) @ n
+
+        dirs = rng.normal(size=(4000, 3))
+        vals = np.array([h(d) for d in dirs])
+        assert vals.min() >= depth - 1e-9
+        # h is piecewise smooth and not convex on the sphere: polish several of the best samples and keep the lowest
+        best = min(minimize(h, dirs[i], method="Nelder-Mead", options={"xatol": 1e-9, "fatol": 1e-12, "maxiter": 3000}).fun
+                   for i in np.argsort(vals)[:10])
+        assert best >= depth - 1e-8 and best - depth < 3e-4, (best, depth)   # nothing below the EPA value, and it is attained
+        checked += 1
+    assert checked >= 15

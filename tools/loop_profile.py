@@ -5,7 +5,7 @@ source functions through the line table (innermost inlined location).  Diagnosti
 import re, collections, bisect, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 lines = open(sys.argv[1]).read().split('\n')
-start = [i for i, l in enumerate(lines) if l.startswith('_ZN12_GLOBAL__N_110env_kernelILi2ELi0EEEvNS_7KParamsEPKf:')][0]
+start = [i for i, l in enumerate(lines) if l.startswith('_ZN12_GLOBAL__N_110env_kernelILi2ELi0ELb0EEEvNS_7KParamsEPKf:')][0]
 end = [i for i in range(start, len(lines)) if lines[i].startswith('.Lfunc_end')][0]
 body = lines[start:end]
 files = {}

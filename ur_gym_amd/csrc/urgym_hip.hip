@@ -99,6 +99,8 @@ struct KParams {
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
   int envs;         // envs per workgroup, 1 .. MAX_ENVS (chosen per launch: see urgym_create / do_step)
+  int big_blocks;   // STEP only: the first big_blocks workgroups serve `envs` envs each, the rest `envs_tail` (two-tier launch
+  int envs_tail;    // geometry: the last round of workgroups is made of smaller, shorter ones; 0 = uniform)
   // prefetched episode records (null / 0 when the feature is off)
   double* rec_d;    // [2][REC_FIELDS][N]
   int32_t* rec_i;   // [2][2][N]: {episode id of the record, status flags of its sampling}
@@ -534,7 +536,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // array is indexed dynamically (that would live in scratch)
   constexpr int OD = (KIND == URGYM_ENV_ORI) ? 18 : ((KIND == URGYM_ENV_OBS) ? 26 : ((KIND == URGYM_ENV_STA) ? 29 : 35));
   constexpr int GD = (KIND == URGYM_ENV_OBS) ? 3 : 6;
-  const int E = P.envs;                      // envs of this workgroup, 1 .. MAX_ENVS
+  // envs of this workgroup (1 .. MAX_ENVS) and the index of its first env / list entry.  STEP launches may be two-tiered.
+  const bool tail_block = (MODE == MODE_STEP) && P.envs_tail > 0 && (int)blockIdx.x >= P.big_blocks;
+  const int E = tail_block ? P.envs_tail : P.envs;
+  const int first = tail_block ? P.big_blocks * P.envs + ((int)blockIdx.x - P.big_blocks) * P.envs_tail : (int)blockIdx.x * P.envs;
   const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
@@ -556,7 +561,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   int list_count = 0;
   if (MODE != MODE_STEP) {
     list_count = (MODE == MODE_PREFETCH) ? min(*P.rcount, P.rcap) : B.done_count[P.pp];
-    if ((int)blockIdx.x * E >= list_count) return;  // uniform for the whole workgroup
+    if (first >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
   // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
@@ -570,7 +575,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // P1 is dropped for STEP.  The last wave holds the fewest / shortest queries (ticket order), which hides its late start.
   constexpr int P1_WAVE = (MODE == MODE_STEP) ? WAVES - 1 : 0;
   if (MODE == MODE_STEP && tid < E) {
-    s_env[tid] = ((int)blockIdx.x * E + tid < N) ? (int)blockIdx.x * E + tid : -1;
+    s_env[tid] = (first + tid < N) ? first + tid : -1;
     s_flags[tid] = 0;
     s_pairs[tid] = 0;
   }
@@ -587,7 +592,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   int n_slot = -1, flags_slot = 0;  // env of slot `lane`
   int key_slot = 0;                 // PREFETCH: the episode id the record is for
   if (p1_lane) {
-    const int idx = blockIdx.x * E + lane;
+    const int idx = first + lane;
     if (MODE == MODE_STEP) n_slot = idx < N ? idx : -1;
     else if (MODE == MODE_PREFETCH) {
       if (idx < list_count) { const int2 ent = P.rlist[idx]; n_slot = ent.x; key_slot = ent.y; }
@@ -1186,7 +1191,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 
   // ---- write-back of the observation rows staged in LDS (coalesced for STEP: the group's rows are contiguous)
   if (MODE == MODE_STEP) {
-    const int base = blockIdx.x * E;
+    const int base = first;
     const int cnt = min(E, N - base);
     for (int i = tid; i < cnt * OD; i += THREADS) B.observation[(size_t)base * OD + i] = s_out[(i / OD) * 47 + (i % OD)];
     for (int i = tid; i < cnt * GD; i += THREADS) {
@@ -1195,7 +1200,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     }
     if (blockIdx.x == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
   } else if (MODE != MODE_PREFETCH) {
-    const int cnt = min(E, list_count - (int)blockIdx.x * E);
+    const int cnt = min(E, list_count - first);
     for (int i = tid; i < cnt * OD; i += THREADS) {
       const int e = i / OD;
       const int se = s_env[e];
@@ -1328,6 +1333,7 @@ struct Handle {
   uint64_t seed = 0;
   int pp = 0;
   int step_envs = GROUP;  // envs per workgroup of the step kernel (see urgym_create)
+  int big_blocks = 0, tail_envs = 0;  // two-tier geometry of the step launch: the first big_blocks workgroups serve step_envs, the rest tail_envs
   int reset_envs = 4;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
   char err[512] = {0};
   // timing
@@ -1433,6 +1439,8 @@ KParams make_params(Handle* h, int copy_final) {
   P.pp = h->pp;
   P.copy_final = copy_final;
   P.envs = GROUP;
+  P.big_blocks = 0;
+  P.envs_tail = 0;
   P.rec_d = h->d_rec;
   P.rec_i = h->d_reci;
   P.rlist = nullptr;
@@ -1452,7 +1460,13 @@ void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream
   envs = envs < 1 ? 1 : (envs > cap ? cap : envs);              // the kernel's LDS is sized for that many
   P.envs = envs;
   if (items < 0) items = h->cfg.num_envs;                       // list-driven launches: an upper bound of the list length
-  dim3 grid((unsigned)((items + envs - 1) / envs)), block(THREADS);
+  long blocks = (items + envs - 1) / envs;
+  if (MODE == MODE_STEP && h->tail_envs > 0 && h->big_blocks > 0 && (long)h->big_blocks * envs < items) {
+    P.big_blocks = h->big_blocks;
+    P.envs_tail = h->tail_envs;
+    blocks = h->big_blocks + (items - (long)h->big_blocks * envs + h->tail_envs - 1) / h->tail_envs;
+  }
+  dim3 grid((unsigned)blocks), block(THREADS);
   // which launches can consume a penetration depth: see need_epa in the kernel
   const bool epa = (MODE != MODE_STEP) || !h->cfg.check_collision;
   switch (h->cfg.env_kind) {
@@ -1710,6 +1724,12 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     if (const char* ov = getenv("URGYM_STEP_ENVS")) {
       const int v = atoi(ov);
       if (v >= 1 && v <= MAX_ENVS) h->step_envs = v;
+    }
+    if (const char* ov = getenv("URGYM_STEP_TIERS")) {  // "E1,B,E2": B workgroups of E1 envs, then workgroups of E2 (tuning / tests)
+      int e1 = 0, b = 0, e2 = 0;
+      if (sscanf(ov, "%d,%d,%d", &e1, &b, &e2) == 3 && e1 >= 1 && e1 <= MAX_ENVS && e2 >= 1 && e2 <= MAX_ENVS && b >= 1) {
+        h->step_envs = e1; h->big_blocks = b; h->tail_envs = e2;
+      }
     }
     if (const char* ov = getenv("URGYM_RESET_ENVS")) {
       const int r = atoi(ov);
