@@ -485,12 +485,16 @@ def test_full_size_properties():
     env3.close()
 
 
-@pytest.mark.parametrize("step_envs,reset_envs", [(5, 1), (37, 3), (64, 64)])
-def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs, reset_envs):
-    """The envs-per-workgroup choices of urgym_create (URGYM_STEP_ENVS / URGYM_RESET_ENVS override them) are pure
-    scheduling: any value must give the oracle's results — odd sizes, one env per reset workgroup, full 64."""
+@pytest.mark.parametrize("step_envs,reset_envs,tiers", [(5, 1, None), (37, 3, None), (64, 64, None), (90, 4, None), (128, 8, None),
+                                                         (64, 4, "100,2,9"), (46, 4, "64,3,17")])
+def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs, reset_envs, tiers):
+    """The envs-per-workgroup choices of urgym_create (URGYM_STEP_ENVS / URGYM_STEP_TIERS / URGYM_RESET_ENVS override them) are
+    pure scheduling: any value must give the oracle's results — odd sizes, one env per reset workgroup, full waves, workgroups
+    of more than one wave's worth of envs (two P1 / P4 waves, link distances through the global scratch), two-tier grids."""
     monkeypatch.setenv("URGYM_STEP_ENVS", str(step_envs))
     monkeypatch.setenv("URGYM_RESET_ENVS", str(reset_envs))
+    if tiers:
+        monkeypatch.setenv("URGYM_STEP_TIERS", tiers)
     kind, n, steps = _abi.ENV_DYN, 333, 30
     env = make_vec("UR5DynReach-v1", num_envs=n, seed=41)
     orc = oracle.OracleEnv(kind, n, threads=8)
@@ -500,7 +504,7 @@ def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs,
     finished = 0
     for t in range(steps):
         a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
-        d, _ = step_both(oracle, kind, env, orc, a, where=f"geometry {step_envs}/{reset_envs} step {t}")
+        d, _ = step_both(oracle, kind, env, orc, a, where=f"geometry {step_envs}/{reset_envs}/{tiers} step {t}")
         finished += d
     assert finished > 5
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
@@ -677,9 +681,11 @@ def test_one_step_reproduces_the_reference_observation_on_the_gpu(oracle, name):
     env.close()
 
 
-@pytest.mark.parametrize("env_id,kind", [KINDS[1], KINDS[3]])
-def test_workbench_link_dist_scope_parity(oracle, env_id, kind):
+@pytest.mark.parametrize("env_id,kind,step_envs", [KINDS[1] + (None,), KINDS[3] + (None,), KINDS[1] + (100,)])
+def test_workbench_link_dist_scope_parity(oracle, monkeypatch, env_id, kind, step_envs):
     """link_dist_scope = URGYM_LINK_DIST_WORKBENCH (per link the minimum over obstacle, table, track; include/urgym.h)."""
+    if step_envs:
+        monkeypatch.setenv("URGYM_STEP_ENVS", str(step_envs))  # two waves' worth of envs per workgroup
     n, steps = 200, 50
     env = make_vec(env_id, num_envs=n, seed=37, link_dist_scope=_abi.LINK_DIST_WORKBENCH)
     orc = oracle.OracleEnv(kind, n, threads=8, link_dist_scope=_abi.LINK_DIST_WORKBENCH)
@@ -727,9 +733,12 @@ def test_check_collision_off_parity(oracle, env_id, kind, n):
     env.close()
 
 
-def test_obs_terminal_collision_reward_uses_penetration_depth(oracle):
+@pytest.mark.parametrize("step_envs", [None, 100])
+def test_obs_terminal_collision_reward_uses_penetration_depth(oracle, monkeypatch, step_envs):
     """ReachObs.compute_reward (reach.py:357-372) reads get_link_distances BEFORE the collision term: on a terminal collision
     step the reward carries 100 * (negative contact distance - last).  Round 1 clamped that distance to -(margins)."""
+    if step_envs:
+        monkeypatch.setenv("URGYM_STEP_ENVS", str(step_envs))  # the EPA phase enumerates the marks of two waves' worth of envs
     n = 2048
     env = make_vec("UR5ObsReach-v1", num_envs=n, seed=47, auto_reset=False)
     orc = oracle.OracleEnv(_abi.ENV_OBS, n, threads=8, auto_reset=0)

@@ -43,7 +43,11 @@ constexpr int GROUP = 64;       // env slots per wave-wide pass
 #define URGYM_MAX_ENVS 64
 #endif
 constexpr int PREFETCH_MAX_ENVS = 32;       // envs per PREFETCH workgroup at most
-constexpr int MAX_ENVS = URGYM_MAX_ENVS;   // most envs one workgroup serves (KParams::envs); bounded by the 53 KB LDS budget of STEP
+constexpr int MAX_ENVS = URGYM_MAX_ENVS;   // most envs one RESET / REFRESH workgroup serves (one wave of per-env lanes)
+// A STEP workgroup may serve up to two waves' worth of envs: with its link distances parked in a global scratch array instead
+// of LDS the per-env LDS footprint is 12 bytes, so the 53.7 KB that three resident workgroups allow are not exceeded, and
+// N = 65536 fits ONE round of resident workgroups (E = 90) instead of two rounds of 46 with a ragged second one.
+constexpr int STEP_MAX_ENVS = 128;
 #ifndef URGYM_WAVES
 #define URGYM_WAVES 4
 #endif
@@ -108,6 +112,7 @@ struct KParams {
                     // episodes after the one it started (refilled synchronously), PREFETCH reads its work from here
   int* rcount;      // number of entries in rlist
   int rcap;         // capacity of rlist
+  double* ld_scratch;  // [5][N]: the link distances of the running step (STEP keeps them here, not in LDS)
   int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
   int* rzero2;      // a second one
   int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
@@ -507,9 +512,12 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // per-env slots (E = P.envs envs per workgroup, <= MAX_ENVS) ...
   // PREFETCH workgroups run UNDER a step kernel: with at most 32 envs and no joint array they need < 55 KB and share a CU with
   // two step workgroups instead of displacing both
-  constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : MAX_ENVS;
+  constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
   constexpr bool LDS_Q = (MODE == MODE_REFRESH);  // RESET / PREFETCH: the joints are the neutral pose, a constant
-  __shared__ double s_dist[5][ME];
+  // link distances of the workgroup's envs: LDS, except STEP (global scratch [5][N], rows of consecutive envs: coalesced; the
+  // cells are written by query lanes and read by the P4 lanes of the SAME workgroup after a barrier)
+  constexpr bool DIST_LDS = (MODE != MODE_STEP);
+  __shared__ double s_dist[5][DIST_LDS ? ME : 1];
   // STEP launches re-derive the joints and the obstacle pose from global memory wherever they are needed (joint_of_step,
   // obstacle_of_step): 6.5 KB less LDS, which is what lets a third workgroup stay resident on the CU.  RESET / REFRESH
   // launches hand them from the sampling lane to the query lanes through LDS (global memory written by this launch is
@@ -552,7 +560,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   const bool need_epa = WITH_EPA && ((KIND == URGYM_ENV_OBS) || !cfg.check_collision || (MODE != MODE_STEP));
   XRef pose_slot{(URGYM_LDS double*)&s_pose[0][0] + tid, THREADS};
   float* const s_out = reinterpret_cast<float*>(&s_pose[0][0]);  // observation rows are staged here once the GJK slots are free
-  static_assert(sizeof(float) * MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
+  static_assert(sizeof(float) * STEP_MAX_ENVS * 47 <= sizeof(double) * GJK_SLOT_DOUBLES * THREADS, "staging must fit");
+  auto dist_cell = [&](int i, int e) -> double* {
+    return DIST_LDS ? (double*)&s_dist[i][DIST_LDS ? e : 0] : &P.ld_scratch[(size_t)i * N + first + e];
+  };
 
   if (blockIdx.x == 0 && tid == 0) {  // (before any early exit)
     if (P.rzero) *P.rzero = 0;
@@ -568,12 +579,12 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
   const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
   if (workbench && tid < E)
-    for (int i = 0; i < 5; i++) s_dist[i][tid] = __longlong_as_double(0x7FF0000000000000LL);
+    for (int i = 0; i < 5; i++) *dist_cell(i, tid) = __longlong_as_double(0x7FF0000000000000LL);
   // STEP: the per-env phase P1 (joint check + culling) runs on the LAST wave while the others already start their obstacle
   // queries — nothing a query needs comes from P1 (joints and obstacle are re-derived from global memory), only the pair
   // masks do, and those are drawn late.  So the slots are initialised here, before the first barrier, and the barrier after
   // P1 is dropped for STEP.  The last wave holds the fewest / shortest queries (ticket order), which hides its late start.
-  constexpr int P1_WAVE = (MODE == MODE_STEP) ? WAVES - 1 : 0;
+  // (with E > 64 the last TWO waves: wave WAVES - G + g serves env slots 64 g .. 64 g + 63, the same lanes as in P4)
   if (MODE == MODE_STEP && tid < E) {
     s_env[tid] = (first + tid < N) ? first + tid : -1;
     s_flags[tid] = 0;
@@ -588,11 +599,12 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
-  const bool p1_lane = (wv == P1_WAVE) && (lane < E);  // E <= 64: one lane per env slot
+  const int p1_slot = (MODE == MODE_STEP) ? (wv - (WAVES - G)) * GROUP + lane : lane;  // env slot this lane serves in P1
+  const bool p1_lane = ((MODE == MODE_STEP) ? (wv >= WAVES - G) : (wv == 0)) && (p1_slot < E);
   int n_slot = -1, flags_slot = 0;  // env of slot `lane`
   int key_slot = 0;                 // PREFETCH: the episode id the record is for
   if (p1_lane) {
-    const int idx = first + lane;
+    const int idx = first + p1_slot;
     if (MODE == MODE_STEP) n_slot = idx < N ? idx : -1;
     else if (MODE == MODE_PREFETCH) {
       if (idx < list_count) { const int2 ent = P.rlist[idx]; n_slot = ent.x; key_slot = ent.y; }
@@ -603,10 +615,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   if ((MODE == MODE_RESET || MODE == MODE_PREFETCH) && wv == 0) {
     int episode_used = 0;
     sample_episode_wave<KIND>(P, pose_slot, E, lane, n_slot, key_slot, MODE == MODE_PREFETCH, flags_slot, episode_used);
-    if (p1_lane) s_key[lane] = (MODE == MODE_PREFETCH) ? key_slot : episode_used + 1;
+    if (p1_lane) s_key[p1_slot] = (MODE == MODE_PREFETCH) ? key_slot : episode_used + 1;
   }
   if (p1_lane) {
-    const int e = lane;
+    const int e = p1_slot;
     const int n = n_slot;
     int flags = flags_slot;
     double q[6] = {0, 0, 0, 0, 0, 0};
@@ -621,7 +633,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         // elbow +-pi, the others +-2 pi) Bullet's limit constraint would act during stepSimulation -- flagged, not altered
         bool over = false;
         for (int i = 0; i < 6; i++) over = over || (fabs(q[i]) > (i == 2 ? 3.141592653589793 : 6.283185307179586));
-        if (over) atomicOr(&s_flags[lane], URGYM_STATUS_JOINT_LIMIT);
+        if (over) atomicOr(&s_flags[p1_slot], URGYM_STATUS_JOINT_LIMIT);
       }
       if (HAS_OBST && LDS_STATE) {
         // reset / refresh: the obstacle goes to its start pose (reach.py:319, 678, 709-710); PREFETCH: the record's
@@ -640,7 +652,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
     }
     if (HAS_OBST && !live)
-      for (int i = 0; i < 5; i++) s_dist[i][e] = (n >= 0) ? __builtin_nan("") : 1e30;
+      for (int i = 0; i < 5; i++) *dist_cell(i, e) = (n >= 0) ? __builtin_nan("") : 1e30;
     // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
     uint32_t pairs = 0;
     if (live && cfg.check_collision && MODE != MODE_RESET && MODE != MODE_PREFETCH) {
@@ -686,7 +698,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   }
   STAMP_TIME(1);
   if (MODE == MODE_STEP) {
-    if (wv == P1_WAVE && lane == 0) __hip_atomic_store(&s_p1done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (wv >= WAVES - G && lane == 0) __hip_atomic_fetch_add(&s_p1done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   } else {
     __syncthreads();
   }
@@ -781,7 +793,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     auto claim_pair = [&]() -> uint32_t {
       int pe = tid % E;
 #pragma unroll 1
-      for (int trip = 0; trip < 2 * MAX_ENVS; trip++, pe = (pe + 1 == E ? 0 : pe + 1)) {
+      for (int trip = 0; trip < 2 * ME; trip++, pe = (pe + 1 == E ? 0 : pe + 1)) {
         uint32_t m = s_pairs[pe];
         while (m) {
           const int b = __ffs((int)m) - 1;
@@ -837,8 +849,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
               atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION | (need_epa ? (1 << (EPA_SHIFT + 5 * body + (lb - 2))) : 0));
             }
             if (run.info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
-            if (workbench) atomicMin(reinterpret_cast<long long*>(&s_dist[lb - 2][e]), sortable(dist));
-            else s_dist[lb - 2][e] = dist;
+            if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
+            else *dist_cell(lb - 2, e) = dist;
           } else {
             const bool hit = (run.info & GJK_PENETRATING) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
             if (hit) atomicOr(&s_flags[e], COLL_BIT);
@@ -848,7 +860,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       }
       // (atomic loads: other waves change both words while this one polls them; a plain read could legally be hoisted)
       const bool more_tickets = __hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_tickets;
-      const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0;
+      const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
       const bool more_pairs = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0;  // (read AFTER the acquire)
       // drawing an item costs the whole wave a set-up (FK + operands), so idle lanes
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
@@ -876,34 +888,46 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  The marks are final
     //      after the barrier, so every wave enumerates the same list and takes every WAVES-th entry.
     if (HAS_OBST && WITH_EPA) {
-      const int marks = (lane < E) ? ((s_flags[lane] & EPA_MASK) >> EPA_SHIFT) : 0;
-      unsigned long long envs_marked = __ballot(marks != 0);
-      if (envs_marked != 0ull) {  // uniform over the workgroup
+      int marks_g[2] = {0, 0};  // env slots 0..63 and 64..127
+      bool any_mark = false;
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int sl = g * GROUP + lane;
+        marks_g[g] = (g < G && sl < E) ? ((s_flags[sl] & EPA_MASK) >> EPA_SHIFT) : 0;
+        any_mark = any_mark || (__ballot(marks_g[g] != 0) != 0ull);
+      }
+      if (any_mark) {  // uniform over the workgroup
         const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
         pose_slot.p = ws.base;    // every lane of the wave stores the (same) operands into the wave's slot
         int counter = 0;
 #pragma unroll 1
-        while (envs_marked) {
-          const int ee = __builtin_ctzll(envs_marked);
-          envs_marked &= envs_marked - 1ull;
-          int me = __shfl(marks, ee);
+        for (int g = 0; g < G; g++) {
+          const int marks = g == 0 ? marks_g[0] : marks_g[1];
+          unsigned long long envs_marked = __ballot(marks != 0);
 #pragma unroll 1
-          while (me) {
-            const int b = __builtin_ctz((unsigned)me);
-            me &= me - 1;
-            if ((counter++ % WAVES) != wv) continue;
-            const int body = b / 5, link = 2 + b - 5 * body;
-            const uint32_t item = (uint32_t)ee | ((uint32_t)(body == 0 ? 3 : (body == 1 ? Q_TABLE : Q_TRACK)) << 8) | ((uint32_t)link << 10) |
-                                  ((body ? 1u : 0u) << 16);
-            if (!setup(item)) continue;
-            epa_wave_sync();
-            bool capped;
-            const double depth = epa_wave(P.graph, shape_a(), shape_b(), ws, lane, capped);
-            if (lane == 0) {
-              const double dist = -(depth + margin_sum());
-              if (workbench) atomicMin(reinterpret_cast<long long*>(&s_dist[lb - 2][e]), sortable(dist));
-              else s_dist[lb - 2][e] = dist;
-              if (capped) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+          while (envs_marked) {
+            const int el = __builtin_ctzll(envs_marked);
+            envs_marked &= envs_marked - 1ull;
+            const int ee = g * GROUP + el;
+            int me = __shfl(marks, el);
+#pragma unroll 1
+            while (me) {
+              const int b = __builtin_ctz((unsigned)me);
+              me &= me - 1;
+              if ((counter++ % WAVES) != wv) continue;
+              const int body = b / 5, link = 2 + b - 5 * body;
+              const uint32_t item = (uint32_t)ee | ((uint32_t)(body == 0 ? 3 : (body == 1 ? Q_TABLE : Q_TRACK)) << 8) | ((uint32_t)link << 10) |
+                                    ((body ? 1u : 0u) << 16);
+              if (!setup(item)) continue;
+              epa_wave_sync();
+              bool capped;
+              const double depth = epa_wave(P.graph, shape_a(), shape_b(), ws, lane, capped);
+              if (lane == 0) {
+                const double dist = -(depth + margin_sum());
+                if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
+                else *dist_cell(lb - 2, e) = dist;
+                if (capped) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+              }
             }
           }
         }
@@ -958,7 +982,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     bool coll = (s_flags[pe] & COLL_BIT) != 0;
     if (HAS_OBST) {
       for (int i = 0; i < 5; i++) {
-        ld_new[i] = workbench ? unsortable(__double_as_longlong(s_dist[i][pe])) : s_dist[i][pe];
+        ld_new[i] = workbench ? unsortable(__double_as_longlong(*dist_cell(i, pe))) : *dist_cell(i, pe);
         if (MODE == MODE_STEP) ld_old[i] = SOA(B.link_dist, i, n, N);
         if (cfg.check_collision && ld_new[i] <= cfg.collision_margin) coll = true;
       }
@@ -1327,6 +1351,7 @@ struct Handle {
   bool bound = false;
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
+  double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
   unsigned short* d_dirmap = nullptr;
@@ -1446,6 +1471,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.rlist = nullptr;
   P.rcount = nullptr;
   P.rcap = 0;
+  P.ld_scratch = h->d_ld_scratch;
   P.rzero = nullptr;
   P.rzero2 = nullptr;
   P.fallback_on = 1;
@@ -1456,7 +1482,7 @@ KParams make_params(Handle* h, int copy_final) {
 
 template <int MODE>
 void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s, long items = -1) {
-  const int cap = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : MAX_ENVS;
+  const int cap = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
   envs = envs < 1 ? 1 : (envs > cap ? cap : envs);              // the kernel's LDS is sized for that many
   P.envs = envs;
   if (items < 0) items = h->cfg.num_envs;                       // list-driven launches: an upper bound of the list length
@@ -1670,23 +1696,25 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     if (r != hipSuccess) return r;
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
-  e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
+  e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
+  if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
   if (e != hipSuccess) {
+    if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
     if (h->d_verts64) hipFree(h->d_verts64);
     if (h->d_recs) hipFree(h->d_recs);
     if (h->d_dirmap) hipFree(h->d_dirmap);
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
   }
-  // Envs per step workgroup (E).  Measured on MI355X (DESIGN.md "launch geometry"): the kernel is bound by the latency of
-  // the GJK iteration chain, a round of resident workgroups takes about the same time almost independently of how full the
-  // chip is, and E = 64 (one hull per wave) is the most efficient shape.  So:
-  //   * N fits one round: the smallest power of two E >= 8 whose ceil(N / E) workgroups are all resident at once;
-  //   * N needs two rounds of 64: E = ceil(N / (2 * slots)) so that the second round is a full one (65536 -> 43);
-  //   * more rounds: E = 64.
-  // URGYM_STEP_ENVS / URGYM_RESET_ENVS override the choices (tuning / tests).
+  // Envs per step workgroup (E <= STEP_MAX_ENVS = 128).  Measured on MI355X (DESIGN.md "launch geometry"): the kernel is bound
+  // by the latency of the GJK iteration chains; a workgroup's lifetime grows slowly with E (145 us at 46 envs, 177 us at 64),
+  // while every additional ROUND of workgroups costs a whole lifetime plus a ragged tail.  So the fewest rounds win:
+  //   * N fits one round of <= 128-env workgroups: E = ceil(N / slots), but at least 8, rounded up to a multiple of 16 below
+  //     64 (128-byte runs of the float64 state arrays) -- 65536 envs -> 90 per workgroup, all 729 resident at once;
+  //   * otherwise R = ceil(N / (128 slots)) rounds of equal workgroups: E = ceil(N / (R slots)).
+  // URGYM_STEP_ENVS / URGYM_STEP_TIERS / URGYM_RESET_ENVS override the choices (tuning / tests).
   {
     int cus = 256, per_cu = 3;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
@@ -1707,14 +1735,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       const long refill = n / 1600;
       slots -= refill < slots / 8 ? refill : slots / 8;
     }
-    long envs = GROUP;
-    if (n <= slots * GROUP) {
-      envs = 8;
-      while (envs < GROUP && (n + envs - 1) / envs > slots) envs *= 2;
-    } else {
-      const long rounds = (n + slots * GROUP - 1) / (slots * GROUP);
-      if (rounds <= 2) envs = (n + slots * rounds - 1) / (slots * rounds);
-    }
+    const long rounds = (n + slots * STEP_MAX_ENVS - 1) / (slots * STEP_MAX_ENVS);
+    long envs = (n + slots * rounds - 1) / (slots * rounds);
+    if (envs < 8) envs = 8;
+    if (envs < GROUP) envs = (envs + 15) / 16 * 16;
+    if (envs > STEP_MAX_ENVS) envs = STEP_MAX_ENVS;
     h->step_envs = (int)envs;
     // auto-reset kernel: ~1 % of the envs finish per step; keep that to about one workgroup per CU (4 envs at N = 65536,
     // 8 at 262144): it is pure latency, smaller workgroups shorten the wave-wide maxima, more than one per CU queue up
@@ -1723,11 +1748,11 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     h->reset_envs = renvs;
     if (const char* ov = getenv("URGYM_STEP_ENVS")) {
       const int v = atoi(ov);
-      if (v >= 1 && v <= MAX_ENVS) h->step_envs = v;
+      if (v >= 1 && v <= STEP_MAX_ENVS) h->step_envs = v;
     }
     if (const char* ov = getenv("URGYM_STEP_TIERS")) {  // "E1,B,E2": B workgroups of E1 envs, then workgroups of E2 (tuning / tests)
       int e1 = 0, b = 0, e2 = 0;
-      if (sscanf(ov, "%d,%d,%d", &e1, &b, &e2) == 3 && e1 >= 1 && e1 <= MAX_ENVS && e2 >= 1 && e2 <= MAX_ENVS && b >= 1) {
+      if (sscanf(ov, "%d,%d,%d", &e1, &b, &e2) == 3 && e1 >= 1 && e1 <= STEP_MAX_ENVS && e2 >= 1 && e2 <= STEP_MAX_ENVS && b >= 1) {
         h->step_envs = e1; h->big_blocks = b; h->tail_envs = e2;
       }
     }
@@ -1771,6 +1796,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_refill, hipEventDisableTiming);
       if (pe != hipSuccess) {
         release_prefetch(h);
+        if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
         if (h->d_verts64) hipFree(h->d_verts64);
         if (h->d_recs) hipFree(h->d_recs);
         if (h->d_dirmap) hipFree(h->d_dirmap);
@@ -1793,6 +1819,7 @@ int urgym_destroy(void* handle) {
   hipSetDevice(h->device);
   release_prefetch(h);
   for (auto e : h->ev) hipEventDestroy(e);
+  if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
   if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
   if (h->d_dirmap) hipFree(h->d_dirmap);
