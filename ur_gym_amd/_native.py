@@ -11,7 +11,8 @@ import subprocess
 from . import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "liburgym_hip.so")
+# URGYM_LIB: another build of the same extension (tuning experiments: tools/exp_*.sh); there is still no fallback of any kind
+LIB_PATH = os.environ.get("URGYM_LIB") or os.path.join(_CSRC, "liburgym_hip.so")
 _lib = None
 
 

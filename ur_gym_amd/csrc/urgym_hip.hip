@@ -55,7 +55,7 @@ constexpr int WAVES = URGYM_WAVES;  // waves per workgroup
 constexpr int THREADS = GROUP * WAVES;
 constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 #ifndef URGYM_REFILL_MIN
-#define URGYM_REFILL_MIN 32
+#define URGYM_REFILL_MIN 16
 #endif
 constexpr int REFILL_MIN = URGYM_REFILL_MIN;
 // bits of the per-env culling mask: table vs links 2..6, track vs links 2..6, the nine self pairs
@@ -113,6 +113,13 @@ struct KParams {
   int* rcount;      // number of entries in rlist
   int rcap;         // capacity of rlist
   double* ld_scratch;  // [5][N]: the link distances of the running step (STEP keeps them here, not in LDS)
+  uint8_t* iter_prev;  // [5][N]: GJK iterations the obstacle query of (link, env) took in the PREVIOUS step (0 = unknown): STEP starts
+                       // the queries it expects to be long first (longest-processing-time-first list scheduling inside a workgroup;
+                       // step-to-step correlation of the counts 0.66 -- the makespan of a workgroup falls by ~16 %, tools/diag)
+  double* sc_scratch;  // [19][N]: STEP's per-env set-up cache, written by the env's P1 lane and read by every later draw of the
+                       // same workgroup: rows 2k / 2k+1 = sin / cos of joint k after the action, rows 12..18 = obstacle position +
+                       // quaternion after this step's motion.  A draw then costs the chain products only (the six float64 sincos of
+                       // a full forward-kinematics pass were three quarters of a set-up).
   int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
   int* rzero2;      // a second one
   int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
@@ -530,6 +537,10 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   __shared__ int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
   __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
   __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
+  // STEP: the obstacle tickets in the order they are handed out (longest expected first), and the histogram of the counting sort
+  constexpr bool LPT = (MODE == MODE_STEP) && (KIND != URGYM_ENV_ORI);
+  __shared__ unsigned short s_perm[LPT ? 5 * STEP_MAX_ENVS : 1];
+  __shared__ int s_hist[LPT ? 64 : 1];     // [0..31] tickets per bin (bin = 31 - expected iterations), [32..63] scatter cursors
   __shared__ int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
   __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
@@ -575,10 +586,11 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if (first >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
+  if (LPT && tid < 64) s_hist[tid] = 0;
   // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
   // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
   const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
-  if (workbench && tid < E)
+  if (workbench && tid < E && (DIST_LDS || first + tid < N))  // (the global scratch has exactly N cells per row)
     for (int i = 0; i < 5; i++) *dist_cell(i, tid) = __longlong_as_double(0x7FF0000000000000LL);
   // STEP: the per-env phase P1 (joint check + culling) runs on the LAST wave while the others already start their obstacle
   // queries — nothing a query needs comes from P1 (joints and obstacle are re-derived from global memory), only the pair
@@ -596,6 +608,34 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); STAMP(10, hw); STAMP(11, xcc); }
 #endif
   __syncthreads();
+  // ---- STEP: order of the obstacle tickets.  Ticket t stands for link 2 + t / E of env slot t % E; it is handed out at position
+  //      pos(t) of a counting sort by the iteration count the same query took one step ago, descending.  Pure scheduling: which
+  //      lane runs a query, and when, never changes its result.
+  const bool lpt = LPT && !workbench && P.iter_prev != nullptr;
+  if (lpt) {
+    int bin[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int t = tid + r * THREADS;
+      if (t < 5 * E) {
+        const int tl = t / E, te = t - tl * E;
+        const int it = (first + te < N) ? (int)P.iter_prev[(size_t)tl * N + first + te] : 0;
+        bin[r] = 31 - (it > 31 ? 31 : it);
+        atomicAdd(&s_hist[bin[r]], 1);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const int t = tid + r * THREADS;
+      if (t < 5 * E) {
+        int start = 0;
+        for (int b = 0; b < bin[r]; b++) start += s_hist[b];
+        s_perm[start + atomicAdd(&s_hist[32 + bin[r]], 1)] = (unsigned short)t;
+      }
+    }
+    __syncthreads();
+  }
 
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
@@ -644,6 +684,20 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       }
     }
     const bool live = (n >= 0 && finite);
+    if (MODE == MODE_STEP && live) {  // the set-up cache of this env (KParams::sc_scratch)
+#pragma unroll 1
+      for (int k = 0; k < 6; k++) {
+        double sn, cs;
+        sincos(joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
+        SOA(P.sc_scratch, 2 * k, n, N) = sn;
+        SOA(P.sc_scratch, 2 * k + 1, n, N) = cs;
+      }
+      if (HAS_OBST) {
+        obstacle_of_step<KIND>(P, n, opos, oq);
+        for (int i = 0; i < 3; i++) SOA(P.sc_scratch, 12 + i, n, N) = opos[i];
+        SOA(P.sc_scratch, 15, n, N) = oq.x; SOA(P.sc_scratch, 16, n, N) = oq.y; SOA(P.sc_scratch, 17, n, N) = oq.z; SOA(P.sc_scratch, 18, n, N) = oq.w;
+      }
+    }
     s_env[e] = live ? n : (n >= 0 ? -2 - n : -1);  // -1 empty; <= -2: env (-2 - v) with non-finite joints
     if (MODE != MODE_STEP) s_flags[e] = flags;      // (STEP: zeroed before the first barrier; queries may already be OR-ing)
     if (LDS_STATE) {
@@ -651,7 +705,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       s_obst[0][e] = opos[0]; s_obst[1][e] = opos[1]; s_obst[2][e] = opos[2];
       s_obst[3][e] = oq.x; s_obst[4][e] = oq.y; s_obst[5][e] = oq.z; s_obst[6][e] = oq.w;
     }
-    if (HAS_OBST && !live)
+    if (HAS_OBST && !live && (DIST_LDS || n >= 0))  // (empty slots have no cell in the global scratch; P4 skips them)
       for (int i = 0; i < 5; i++) *dist_cell(i, e) = (n >= 0) ? __builtin_nan("") : 1e30;
     // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
     uint32_t pairs = 0;
@@ -662,7 +716,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         double sn, cs;
-        sincos(q[k], &sn, &cs);
+        if (MODE == MODE_STEP) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }  // (this lane stored them above)
+        else sincos(q[k], &sn, &cs);
         fk_joint(T, k, sn, cs);
         const int link = k + 1;
         const double* c = c_tab.capsule[k];
@@ -742,6 +797,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       return n2 > 1e-12 ? d * (1.0 / sqrt(n2)) : d3(0, 1, 0);
     };
     // builds the operands of one work item (e | kind << 8 | lb << 10 | la << 13); false when there is nothing to run
+    // p1_ok: the P1 lanes of this workgroup have published (s_p1done acquired) -- their set-up cache may be read
+    bool p1_ok = false;
     auto setup = [&](uint32_t item) -> bool {
       e = item & 255;
       kind = (item >> 8) & 3;
@@ -750,7 +807,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       la = (item >> 13) & 7;
       const int n = s_env[e];
       if (n < 0) return false;
-      if (MODE == MODE_STEP) {  // P1 may not have judged this env yet: non-finite joints -> no query (same rule as P1)
+      const bool cached = (MODE == MODE_STEP) && p1_ok;  // (then s_env already carries P1's verdict on the joints)
+      if (MODE == MODE_STEP && !cached) {  // P1 may not have judged this env yet: non-finite joints -> no query (same rule as P1)
         bool finite = true;
         for (int k = 0; k < 6; k++) finite = finite && (fabs(joint_of_step<MODE>(P, actions, n, k)) < 1.0e6);
         if (!finite) return false;
@@ -759,7 +817,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 #pragma unroll 1
       for (int k = 0; k < lb; k++) {
         double sn, cs;
-        sincos(LDS_Q ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
+        if (cached) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }
+        else sincos(LDS_Q ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
         fk_joint(T, k, sn, cs);
         if (k + 1 == la) TA = T;
       }
@@ -768,6 +827,9 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         if (LDS_STATE) {
           quat_to_rot(Q4{s_obst[3][e], s_obst[4][e], s_obst[5][e], s_obst[6][e]}, To.r);
           To.t = d3(s_obst[0][e], s_obst[1][e], s_obst[2][e]);
+        } else if (cached) {
+          quat_to_rot(Q4{SOA(P.sc_scratch, 15, n, N), SOA(P.sc_scratch, 16, n, N), SOA(P.sc_scratch, 17, n, N), SOA(P.sc_scratch, 18, n, N)}, To.r);
+          To.t = d3(SOA(P.sc_scratch, 12, n, N), SOA(P.sc_scratch, 13, n, N), SOA(P.sc_scratch, 14, n, N));
         } else {
           double op[3];
           Q4 oqs;
@@ -819,6 +881,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     };
     const int n_tickets = HAS_OBST ? (workbench ? 15 : 5) * E : 0;
     auto ticket_item = [&](int t) -> uint32_t {
+      if (lpt) t = s_perm[t];
       const int body = t / (5 * E), r = t - body * 5 * E;  // 0 obstacle, then (WORKBENCH) 1 table, 2 track
       const int tl = r / E, te = r - tl * E, link = 2 + tl;
       if (body == 0) return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
@@ -828,6 +891,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     GjkRun run;
     bool busy = false;
     STAMP_TIME(2);
+    if (MODE == MODE_STEP) p1_ok = __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
     if (tid < n_tickets) {
       busy = setup(ticket_item(tid));
       if (busy) gjk_begin(run, v0);
@@ -849,6 +913,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
               atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION | (need_epa ? (1 << (EPA_SHIFT + 5 * body + (lb - 2))) : 0));
             }
             if (run.info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
+            if (lpt && kind == 3) P.iter_prev[(size_t)(lb - 2) * N + s_env[e]] = (uint8_t)(run.iter > 255 ? 255 : run.iter);
             if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
             else *dist_cell(lb - 2, e) = dist;
           } else {
@@ -862,6 +927,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       const bool more_tickets = __hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_tickets;
       const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
       const bool more_pairs = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0;  // (read AFTER the acquire)
+      if (MODE == MODE_STEP) p1_ok = p1_published;
       // drawing an item costs the whole wave a set-up (FK + operands), so idle lanes
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
       const int idle_lanes = __popcll(__ballot(!busy));
@@ -899,6 +965,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       if (any_mark) {  // uniform over the workgroup
         const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
         pose_slot.p = ws.base;    // every lane of the wave stores the (same) operands into the wave's slot
+        if (MODE == MODE_STEP) p1_ok = true;
         int counter = 0;
 #pragma unroll 1
         for (int g = 0; g < G; g++) {
@@ -960,6 +1027,9 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       if (LDS_STATE) {
         opos[0] = s_obst[0][pe]; opos[1] = s_obst[1][pe]; opos[2] = s_obst[2][pe];
         oq = Q4{s_obst[3][pe], s_obst[4][pe], s_obst[5][pe], s_obst[6][pe]};
+      } else if (s_env[pe] >= 0) {  // the P1 lane of this env (this very lane) cached the advanced pose
+        for (int i = 0; i < 3; i++) opos[i] = SOA(P.sc_scratch, 12 + i, n, N);
+        oq = Q4{SOA(P.sc_scratch, 15, n, N), SOA(P.sc_scratch, 16, n, N), SOA(P.sc_scratch, 17, n, N), SOA(P.sc_scratch, 18, n, N)};
       } else {
         obstacle_of_step<KIND>(P, n, opos, oq);
       }
@@ -1352,6 +1422,8 @@ struct Handle {
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
   double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
+  double* d_sc_scratch = nullptr;  // [19][N] set-up cache of the running step
+  uint8_t* d_iter_prev = nullptr;  // [5][N] iteration counts of the previous step's obstacle queries
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
   unsigned short* d_dirmap = nullptr;
@@ -1472,6 +1544,8 @@ KParams make_params(Handle* h, int copy_final) {
   P.rcount = nullptr;
   P.rcap = 0;
   P.ld_scratch = h->d_ld_scratch;
+  P.sc_scratch = h->d_sc_scratch;
+  P.iter_prev = h->d_iter_prev;
   P.rzero = nullptr;
   P.rzero2 = nullptr;
   P.fallback_on = 1;
@@ -1697,11 +1771,18 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * 19 * (size_t)cfg->num_envs);
+  if (e == hipSuccess && !(getenv("URGYM_LPT") && atoi(getenv("URGYM_LPT")) == 0)) {  // URGYM_LPT=0: tickets in plain order (tuning / tests)
+    e = hipMalloc((void**)&h->d_iter_prev, 5 * (size_t)cfg->num_envs);
+    if (e == hipSuccess) e = hipMemset(h->d_iter_prev, 0, 5 * (size_t)cfg->num_envs);
+  }
   if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
   if (e != hipSuccess) {
     if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
+    if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
+    if (h->d_iter_prev) hipFree(h->d_iter_prev);
     if (h->d_verts64) hipFree(h->d_verts64);
     if (h->d_recs) hipFree(h->d_recs);
     if (h->d_dirmap) hipFree(h->d_dirmap);
@@ -1797,6 +1878,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (pe != hipSuccess) {
         release_prefetch(h);
         if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
+        if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
+        if (h->d_iter_prev) hipFree(h->d_iter_prev);
         if (h->d_verts64) hipFree(h->d_verts64);
         if (h->d_recs) hipFree(h->d_recs);
         if (h->d_dirmap) hipFree(h->d_dirmap);
@@ -1820,6 +1903,8 @@ int urgym_destroy(void* handle) {
   release_prefetch(h);
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
+  if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
+  if (h->d_iter_prev) hipFree(h->d_iter_prev);
   if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
   if (h->d_dirmap) hipFree(h->d_dirmap);
