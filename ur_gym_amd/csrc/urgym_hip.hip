@@ -113,9 +113,6 @@ struct KParams {
   int* rcount;      // number of entries in rlist
   int rcap;         // capacity of rlist
   double* ld_scratch;  // [5][N]: the link distances of the running step (STEP keeps them here, not in LDS)
-  uint8_t* iter_prev;  // [5][N]: GJK iterations the obstacle query of (link, env) took in the PREVIOUS step (0 = unknown): STEP starts
-                       // the queries it expects to be long first (longest-processing-time-first list scheduling inside a workgroup;
-                       // step-to-step correlation of the counts 0.66 -- the makespan of a workgroup falls by ~16 %, tools/diag)
   double* sc_scratch;  // [19][N]: STEP's per-env set-up cache, written by the env's P1 lane and read by every later draw of the
                        // same workgroup: rows 2k / 2k+1 = sin / cos of joint k after the action, rows 12..18 = obstacle position +
                        // quaternion after this step's motion.  A draw then costs the chain products only (the six float64 sincos of
@@ -537,10 +534,6 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   __shared__ int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
   __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
   __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
-  // STEP: the obstacle tickets in the order they are handed out (longest expected first), and the histogram of the counting sort
-  constexpr bool LPT = (MODE == MODE_STEP) && (KIND != URGYM_ENV_ORI);
-  __shared__ unsigned short s_perm[LPT ? 5 * STEP_MAX_ENVS : 1];
-  __shared__ int s_hist[LPT ? 64 : 1];     // [0..31] tickets per bin (bin = 31 - expected iterations), [32..63] scatter cursors
   __shared__ int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
   __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
@@ -586,7 +579,6 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     if (first >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
-  if (LPT && tid < 64) s_hist[tid] = 0;
   // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
   // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
   const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
@@ -608,35 +600,6 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); STAMP(10, hw); STAMP(11, xcc); }
 #endif
   __syncthreads();
-  // ---- STEP: order of the obstacle tickets.  Ticket t stands for link 2 + t / E of env slot t % E; it is handed out at position
-  //      pos(t) of a counting sort by the iteration count the same query took one step ago, descending.  Pure scheduling: which
-  //      lane runs a query, and when, never changes its result.
-  const bool lpt = LPT && !workbench && P.iter_prev != nullptr;
-  if (lpt) {
-    int bin[3] = {0, 0, 0};
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const int t = tid + r * THREADS;
-      if (t < 5 * E) {
-        const int tl = t / E, te = t - tl * E;
-        const int it = (first + te < N) ? (int)P.iter_prev[(size_t)tl * N + first + te] : 0;
-        bin[r] = 31 - (it > 31 ? 31 : it);
-        atomicAdd(&s_hist[bin[r]], 1);
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const int t = tid + r * THREADS;
-      if (t < 5 * E) {
-        int start = 0;
-        for (int b = 0; b < bin[r]; b++) start += s_hist[b];
-        s_perm[start + atomicAdd(&s_hist[32 + bin[r]], 1)] = (unsigned short)t;
-      }
-    }
-    __syncthreads();
-  }
-
   // ---- P1 (waves 0..G-1, one lane per env slot): which env, joint update, obstacle motion, and the conservative
   //      bounding-capsule culling of the table / track / self pairs of check_collision (pyb_setup.py:407-427) -> LDS
   const int p1_slot = (MODE == MODE_STEP) ? (wv - (WAVES - G)) * GROUP + lane : lane;  // env slot this lane serves in P1
@@ -881,7 +844,6 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     };
     const int n_tickets = HAS_OBST ? (workbench ? 15 : 5) * E : 0;
     auto ticket_item = [&](int t) -> uint32_t {
-      if (lpt) t = s_perm[t];
       const int body = t / (5 * E), r = t - body * 5 * E;  // 0 obstacle, then (WORKBENCH) 1 table, 2 track
       const int tl = r / E, te = r - tl * E, link = 2 + tl;
       if (body == 0) return (uint32_t)te | (3u << 8) | ((uint32_t)link << 10);
@@ -913,7 +875,6 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
               atomicOr(&s_flags[e], URGYM_STATUS_PENETRATION | (need_epa ? (1 << (EPA_SHIFT + 5 * body + (lb - 2))) : 0));
             }
             if (run.info & GJK_ITERCAP) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
-            if (lpt && kind == 3) P.iter_prev[(size_t)(lb - 2) * N + s_env[e]] = (uint8_t)(run.iter > 255 ? 255 : run.iter);
             if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
             else *dist_cell(lb - 2, e) = dist;
           } else {
@@ -1423,7 +1384,6 @@ struct Handle {
   int obs_dim = 0, goal_dim = 0;
   double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
   double* d_sc_scratch = nullptr;  // [19][N] set-up cache of the running step
-  uint8_t* d_iter_prev = nullptr;  // [5][N] iteration counts of the previous step's obstacle queries
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
   unsigned short* d_dirmap = nullptr;
@@ -1545,7 +1505,6 @@ KParams make_params(Handle* h, int copy_final) {
   P.rcap = 0;
   P.ld_scratch = h->d_ld_scratch;
   P.sc_scratch = h->d_sc_scratch;
-  P.iter_prev = h->d_iter_prev;
   P.rzero = nullptr;
   P.rzero2 = nullptr;
   P.fallback_on = 1;
@@ -1772,17 +1731,12 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   };
   e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
   if (e == hipSuccess) e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * 19 * (size_t)cfg->num_envs);
-  if (e == hipSuccess && !(getenv("URGYM_LPT") && atoi(getenv("URGYM_LPT")) == 0)) {  // URGYM_LPT=0: tickets in plain order (tuning / tests)
-    e = hipMalloc((void**)&h->d_iter_prev, 5 * (size_t)cfg->num_envs);
-    if (e == hipSuccess) e = hipMemset(h->d_iter_prev, 0, 5 * (size_t)cfg->num_envs);
-  }
   if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
   if (e != hipSuccess) {
     if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
     if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-    if (h->d_iter_prev) hipFree(h->d_iter_prev);
     if (h->d_verts64) hipFree(h->d_verts64);
     if (h->d_recs) hipFree(h->d_recs);
     if (h->d_dirmap) hipFree(h->d_dirmap);
@@ -1879,8 +1833,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
         release_prefetch(h);
         if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
         if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-        if (h->d_iter_prev) hipFree(h->d_iter_prev);
-        if (h->d_verts64) hipFree(h->d_verts64);
+            if (h->d_verts64) hipFree(h->d_verts64);
         if (h->d_recs) hipFree(h->d_recs);
         if (h->d_dirmap) hipFree(h->d_dirmap);
         delete h;
@@ -1904,7 +1857,6 @@ int urgym_destroy(void* handle) {
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
   if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-  if (h->d_iter_prev) hipFree(h->d_iter_prev);
   if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
   if (h->d_dirmap) hipFree(h->d_dirmap);
