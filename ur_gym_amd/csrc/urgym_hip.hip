@@ -647,7 +647,8 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       }
     }
     const bool live = (n >= 0 && finite);
-    if (MODE == MODE_STEP && live) {  // the set-up cache of this env (KParams::sc_scratch)
+    const bool use_cache = (MODE == MODE_STEP) && P.sc_scratch != nullptr;
+    if (use_cache && live) {  // the set-up cache of this env (KParams::sc_scratch)
 #pragma unroll 1
       for (int k = 0; k < 6; k++) {
         double sn, cs;
@@ -679,7 +680,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 #pragma unroll
       for (int k = 0; k < 6; k++) {
         double sn, cs;
-        if (MODE == MODE_STEP) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }  // (this lane stored them above)
+        if (use_cache) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }  // (this lane stored them above)
         else sincos(q[k], &sn, &cs);
         fk_joint(T, k, sn, cs);
         const int link = k + 1;
@@ -770,7 +771,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       la = (item >> 13) & 7;
       const int n = s_env[e];
       if (n < 0) return false;
-      const bool cached = (MODE == MODE_STEP) && p1_ok;  // (then s_env already carries P1's verdict on the joints)
+      const bool cached = (MODE == MODE_STEP) && p1_ok && P.sc_scratch != nullptr;  // (then s_env already carries P1's verdict on the joints)
       if (MODE == MODE_STEP && !cached) {  // P1 may not have judged this env yet: non-finite joints -> no query (same rule as P1)
         bool finite = true;
         for (int k = 0; k < 6; k++) finite = finite && (fabs(joint_of_step<MODE>(P, actions, n, k)) < 1.0e6);
@@ -988,7 +989,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       if (LDS_STATE) {
         opos[0] = s_obst[0][pe]; opos[1] = s_obst[1][pe]; opos[2] = s_obst[2][pe];
         oq = Q4{s_obst[3][pe], s_obst[4][pe], s_obst[5][pe], s_obst[6][pe]};
-      } else if (s_env[pe] >= 0) {  // the P1 lane of this env (this very lane) cached the advanced pose
+      } else if (s_env[pe] >= 0 && P.sc_scratch != nullptr) {  // the P1 lane of this env (this very lane) cached the advanced pose
         for (int i = 0; i < 3; i++) opos[i] = SOA(P.sc_scratch, 12 + i, n, N);
         oq = Q4{SOA(P.sc_scratch, 15, n, N), SOA(P.sc_scratch, 16, n, N), SOA(P.sc_scratch, 17, n, N), SOA(P.sc_scratch, 18, n, N)};
       } else {
@@ -1730,7 +1731,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
-  if (e == hipSuccess) e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * 19 * (size_t)cfg->num_envs);
+  if (e == hipSuccess && !(getenv("URGYM_SETUP_CACHE") && atoi(getenv("URGYM_SETUP_CACHE")) == 0))  // =0: every draw recomputes (tuning / tests)
+    e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * 19 * (size_t)cfg->num_envs);
   if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
