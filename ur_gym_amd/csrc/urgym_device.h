@@ -541,9 +541,10 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
 //   rows 8..10 (cols 1..63) as uint16 rim candidates: the directed edges of the faces that see the new point
 //   row 11 (cols 1..63) as uint8      free face slots in ascending order
 //   M[12 + 4 (f / 64) + k][f % 64]    plane of face f: unit normal (k = 0..2) and offset d (k = 3)   (rows 12..23)
-// Lane c owns the faces f = c, c + 64, c + 128.
-constexpr int EPA_MAX_VERTS = 80, EPA_MAX_FACES = 192;
-constexpr double EPA_TOL = 1.0e-9;
+// Lane c owns the faces f = c and c + 64.
+constexpr int EPA_MAX_VERTS = 48, EPA_MAX_FACES = 128;   // (the oracle's header comment has the census behind the cap)
+constexpr int EPA_FACE_GROUPS = EPA_MAX_FACES / 64;       // faces per lane
+constexpr double EPA_TOL = 1.0e-9, EPA_CAP_RESIDUAL = 1.0e-5;
 #if !defined(URGYM_HOST_HARNESS)
 struct EpaWs {
   URGYM_LDS double* base;  // &M[0][0]
@@ -590,7 +591,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
     const D3 p0 = supp(d3(t, t, t)), p1 = supp(d3(t, -t, -t)), p2 = supp(d3(-t, t, -t)), p3 = supp(d3(-t, -t, t));
     if (lane == 0) { ws.set_point(0, p0); ws.set_point(1, p1); ws.set_point(2, p2); ws.set_point(3, p3); }
 #pragma unroll
-    for (int gi = 0; gi < 3; gi++) *ws.face_word(lane + 64 * gi) = 0;
+    for (int gi = 0; gi < EPA_FACE_GROUPS; gi++) *ws.face_word(lane + 64 * gi) = 0;
     epa_wave_sync();
     if (lane < 4) {
       // faces of the tetrahedron 0123, turned outward
@@ -615,7 +616,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
     double bd = 1.7e308;
     int bf = 1 << 20;
 #pragma unroll
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < EPA_FACE_GROUPS; gi++) {
       const int f = lane + 64 * gi;
       const bool alive = ((*ws.face_word(f)) >> 24) & 1;
       const double d = *ws.plane(f, 3);
@@ -634,17 +635,17 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
     const D3 w = supp(nb);
     const double gain = dot(nb, w) - db;
     if (gain <= EPA_TOL || nv >= EPA_MAX_VERTS) {
-      capped = gain > EPA_TOL;
+      capped = gain > EPA_CAP_RESIDUAL;
       depth = db > 0.0 ? db : 0.0;
       break;
     }
     // (3) faces that see w die; their directed edges become rim candidates in ascending slot order
     int nvis_before = 0, nc;
     {
-      bool vis[3];
-      int word[3];
+      bool vis[EPA_FACE_GROUPS];
+      int word[EPA_FACE_GROUPS];
 #pragma unroll
-      for (int gi = 0; gi < 3; gi++) {
+      for (int gi = 0; gi < EPA_FACE_GROUPS; gi++) {
         const int f = lane + 64 * gi;
         word[gi] = *ws.face_word(f);
         const bool alive = (word[gi] >> 24) & 1, degen = (word[gi] >> 25) & 1;
@@ -652,7 +653,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
         vis[gi] = alive && (degen || dot(n, w) - *ws.plane(f, 3) > 1e-14);
       }
 #pragma unroll
-      for (int gi = 0; gi < 3; gi++) {
+      for (int gi = 0; gi < EPA_FACE_GROUPS; gi++) {
         const unsigned long long m = __ballot(vis[gi]);
         if (vis[gi]) {
           const int rank = nvis_before + __popcll(m & ((1ull << lane) - 1ull));
@@ -670,7 +671,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
     // (4) the free slots, ascending
     int nfree = 0;
 #pragma unroll
-    for (int gi = 0; gi < 3; gi++) {
+    for (int gi = 0; gi < EPA_FACE_GROUPS; gi++) {
       const int f = lane + 64 * gi;
       const bool fr = !(((*ws.face_word(f)) >> 24) & 1);
       const unsigned long long m = __ballot(fr);

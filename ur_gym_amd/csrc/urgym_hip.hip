@@ -912,57 +912,58 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     }
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
-    __syncthreads();
-    // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  The marks are final
-    //      after the barrier, so every wave enumerates the same list and takes every WAVES-th entry.
-    if (HAS_OBST && WITH_EPA) {
-      int marks_g[2] = {0, 0};  // env slots 0..63 and 64..127
-      bool any_mark = false;
-#pragma unroll
-      for (int g = 0; g < 2; g++) {
+    // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  A wave that has left
+    //      the pool serves the marks that exist by then -- in the shadow of the other waves' last queries -- and every wave
+    //      serves what is left after the barrier.  A mark is claimed by clearing its bit, so each is served exactly once.
+    auto epa_pass = [&]() {
+      const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
+      bool armed = false;
+#pragma unroll 1
+      for (int g = 0; g < G; g++) {
         const int sl = g * GROUP + lane;
-        marks_g[g] = (g < G && sl < E) ? ((s_flags[sl] & EPA_MASK) >> EPA_SHIFT) : 0;
-        any_mark = any_mark || (__ballot(marks_g[g] != 0) != 0ull);
-      }
-      if (any_mark) {  // uniform over the workgroup
-        const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
-        pose_slot.p = ws.base;    // every lane of the wave stores the (same) operands into the wave's slot
-        if (MODE == MODE_STEP) p1_ok = true;
-        int counter = 0;
+        const int marks = (sl < E) ? ((__hip_atomic_load(&s_flags[sl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & EPA_MASK) >> EPA_SHIFT) : 0;
+        unsigned long long envs_marked = __ballot(marks != 0);
 #pragma unroll 1
-        for (int g = 0; g < G; g++) {
-          const int marks = g == 0 ? marks_g[0] : marks_g[1];
-          unsigned long long envs_marked = __ballot(marks != 0);
+        while (envs_marked) {
+          const int el = __builtin_ctzll(envs_marked);
+          envs_marked &= envs_marked - 1ull;
+          const int ee = g * GROUP + el;
+          int me = __shfl(marks, el);
 #pragma unroll 1
-          while (envs_marked) {
-            const int el = __builtin_ctzll(envs_marked);
-            envs_marked &= envs_marked - 1ull;
-            const int ee = g * GROUP + el;
-            int me = __shfl(marks, el);
-#pragma unroll 1
-            while (me) {
-              const int b = __builtin_ctz((unsigned)me);
-              me &= me - 1;
-              if ((counter++ % WAVES) != wv) continue;
-              const int body = b / 5, link = 2 + b - 5 * body;
-              const uint32_t item = (uint32_t)ee | ((uint32_t)(body == 0 ? 3 : (body == 1 ? Q_TABLE : Q_TRACK)) << 8) | ((uint32_t)link << 10) |
-                                    ((body ? 1u : 0u) << 16);
-              if (!setup(item)) continue;
-              epa_wave_sync();
-              bool capped;
-              const double depth = epa_wave(P.graph, shape_a(), shape_b(), ws, lane, capped);
-              if (lane == 0) {
-                const double dist = -(depth + margin_sum());
-                if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
-                else *dist_cell(lb - 2, e) = dist;
-                if (capped) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
-              }
+          while (me) {
+            const int b = __builtin_ctz((unsigned)me);
+            me &= me - 1;
+            int mine = 0;
+            if (lane == 0) mine = (atomicAnd(&s_flags[ee], ~(1 << (EPA_SHIFT + b))) >> (EPA_SHIFT + b)) & 1;
+            if (!__shfl(mine, 0)) continue;  // another wave took it
+            if (!armed) {  // every lane of the wave stores the (same) operands into the wave's slot
+              pose_slot.p = ws.base;
+              if (MODE == MODE_STEP) p1_ok = true;  // (a mark exists only once P1 has published: its query was drawn after it ... or ran without the cache)
+              armed = true;
+            }
+            const int body = b / 5, link = 2 + b - 5 * body;
+            const uint32_t item = (uint32_t)ee | ((uint32_t)(body == 0 ? 3 : (body == 1 ? Q_TABLE : Q_TRACK)) << 8) | ((uint32_t)link << 10) |
+                                  ((body ? 1u : 0u) << 16);
+            if (!setup(item)) continue;
+            epa_wave_sync();
+            bool capped;
+            const double depth = epa_wave(P.graph, shape_a(), shape_b(), ws, lane, capped);
+            if (lane == 0) {
+              const double dist = -(depth + margin_sum());
+              if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
+              else *dist_cell(lb - 2, e) = dist;
+              if (capped) atomicOr(&s_flags[e], URGYM_STATUS_GJK_ITER);
             }
           }
         }
-        pose_slot.p = (URGYM_LDS double*)&s_pose[0][0] + tid;
-        __syncthreads();
       }
+      if (armed) pose_slot.p = (URGYM_LDS double*)&s_pose[0][0] + tid;
+    };
+    if (HAS_OBST && WITH_EPA) epa_pass();
+    __syncthreads();
+    if (HAS_OBST && WITH_EPA) {
+      epa_pass();
+      __syncthreads();
     }
   }
   STAMP_TIME(6);
