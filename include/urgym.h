@@ -161,10 +161,13 @@ int urgym_config_default(int env_kind, int num_envs, urgym_config* cfg);
 int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
 
 /* Replaces UR5*ReachEnv.__init__ (ur_tasks.py:37-90): builds the constant scene/robot tables on `device` (hull neighbour
- * records, direction maps) and fixes the launch geometry for cfg->num_envs.  Environment variables read here, all optional
- * and none of them changes a result: URGYM_STEP_ENVS / URGYM_RESET_ENVS (envs per workgroup of the step / auto-reset
- * kernel, 1..64; tuning and tests), URGYM_PREFETCH (0: reset finished envs with a kernel after each step instead of inline
- * from prefetched episode records), URGYM_VERBOSE (print the chosen geometry to stderr). */
+ * records, direction maps), allocates the library's own scratch (link distances and set-up cache of the running step, episode
+ * records) and fixes the launch geometry for cfg->num_envs.  Environment variables read here, all optional and none of them
+ * changes a result (scheduling / tuning / tests): URGYM_STEP_ENVS (envs per workgroup of the step kernel, 1..128),
+ * URGYM_STEP_TIERS="E1,B,E2" (B workgroups of E1 envs, then workgroups of E2), URGYM_RESET_ENVS (envs per workgroup of the
+ * auto-reset kernel, 1..64), URGYM_PREFETCH (0: reset finished envs with a kernel after each step instead of inline from
+ * prefetched episode records), URGYM_SETUP_CACHE (0: every draw of a query recomputes the joint sines / cosines instead of
+ * reading them from the per-env cache), URGYM_VERBOSE (print the chosen geometry to stderr). */
 int urgym_create(const urgym_config* cfg, int device, void** handle);
 int urgym_destroy(void* handle);
 

@@ -36,6 +36,7 @@
 
 using namespace urgym;
 
+
 namespace {
 
 constexpr int GROUP = 64;       // env slots per wave-wide pass
@@ -534,6 +535,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   __shared__ int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
   __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
   __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
+  __shared__ int s_left;                   // waves that have left the work pool (the EPA service below polls it)
   __shared__ int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
   __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
@@ -578,7 +580,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     list_count = (MODE == MODE_PREFETCH) ? min(*P.rcount, P.rcap) : B.done_count[P.pp];
     if (first >= list_count) return;  // uniform for the whole workgroup
   }
-  if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; }
+  if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; s_left = 0; }
   // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
   // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
   const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
@@ -913,9 +915,11 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
     // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  A wave that has left
-    //      the pool serves the marks that exist by then -- in the shadow of the other waves' last queries -- and every wave
-    //      serves what is left after the barrier.  A mark is claimed by clearing its bit, so each is served exactly once.
-    auto epa_pass = [&]() {
+    //      the pool turns into a service wave: it keeps looking for marks and serves them while the other waves still iterate
+    //      (overlapping cores are found within a few GJK iterations, an EPA takes 70-250 us: starting it at once instead of
+    //      after the pool has drained hides most of it), until every wave has left the pool and no mark is unclaimed.  A mark is
+    //      claimed by clearing its bit, so each is served exactly once.
+    auto epa_pass = [&]() -> bool {
       const EpaWs ws{(URGYM_LDS double*)&s_pose[0][0] + GROUP * wv, THREADS};
       bool armed = false;
 #pragma unroll 1
@@ -958,13 +962,20 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
         }
       }
       if (armed) pose_slot.p = (URGYM_LDS double*)&s_pose[0][0] + tid;
+      return armed;
     };
-    if (HAS_OBST && WITH_EPA) epa_pass();
-    __syncthreads();
     if (HAS_OBST && WITH_EPA) {
-      epa_pass();
-      __syncthreads();
+      if (lane == 0) __hip_atomic_fetch_add(&s_left, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (its marks are all set)
+#pragma unroll 1
+      for (;;) {
+        // read the count BEFORE looking for marks: a mark set by a wave that had left by then is visible to the pass below
+        const int left = __hip_atomic_load(&s_left, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool served = epa_pass();
+        if (!served && left >= WAVES) break;
+        if (!served) __builtin_amdgcn_s_sleep(16);
+      }
     }
+    __syncthreads();
   }
   STAMP_TIME(6);
 
@@ -1749,8 +1760,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   // Envs per step workgroup (E <= STEP_MAX_ENVS = 128).  Measured on MI355X (DESIGN.md "launch geometry"): the kernel is bound
   // by the latency of the GJK iteration chains; a workgroup's lifetime grows slowly with E (145 us at 46 envs, 177 us at 64),
   // while every additional ROUND of workgroups costs a whole lifetime plus a ragged tail.  So the fewest rounds win:
-  //   * N fits one round of <= 128-env workgroups: E = ceil(N / slots), but at least 8, rounded up to a multiple of 16 below
-  //     64 (128-byte runs of the float64 state arrays) -- 65536 envs -> 90 per workgroup, all 729 resident at once;
+  //   * N fits one round of <= 128-env workgroups: E = ceil(N / slots), but at least 8, rounded up to a multiple of 8 below
+  //     64 (64-byte runs of the float64 state arrays) -- 65536 envs -> 91 per workgroup, all 721 resident at once; 16384 -> 24;
   //   * otherwise R = ceil(N / (128 slots)) rounds of equal workgroups: E = ceil(N / (R slots)).
   // URGYM_STEP_ENVS / URGYM_STEP_TIERS / URGYM_RESET_ENVS override the choices (tuning / tests).
   {
@@ -1776,7 +1787,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     const long rounds = (n + slots * STEP_MAX_ENVS - 1) / (slots * STEP_MAX_ENVS);
     long envs = (n + slots * rounds - 1) / (slots * rounds);
     if (envs < 8) envs = 8;
-    if (envs < GROUP) envs = (envs + 15) / 16 * 16;
+    if (envs < GROUP) envs = (envs + 7) / 8 * 8;
     if (envs > STEP_MAX_ENVS) envs = STEP_MAX_ENVS;
     h->step_envs = (int)envs;
     // auto-reset kernel: ~1 % of the envs finish per step; keep that to about one workgroup per CU (4 envs at N = 65536,
