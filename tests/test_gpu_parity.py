@@ -796,3 +796,24 @@ def test_reset_with_the_same_seed_reproduces_the_episode():
             v[:, 24:30] = 0
         assert torch.equal(x, v), k
     env.close()
+
+
+@pytest.mark.parametrize("prefetch", ["0", "1"])
+def test_ori_auto_reset_paths_match_oracle(oracle, monkeypatch, prefetch):
+    """UR5OriReach-v1 resets finished envs inside the step kernel (its reset is one goal draw); URGYM_PREFETCH=0 selects the RESET
+    kernel after each step instead.  Both against the oracle, through collisions, successes and the 100-step truncation."""
+    monkeypatch.setenv("URGYM_PREFETCH", prefetch)
+    kind, n, steps = _abi.ENV_ORI, 300, 110
+    env = make_vec("UR5OriReach-v1", num_envs=n, seed=59)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    env.reset(seed=59)
+    orc.reset(seed=59)
+    rng = np.random.default_rng(59)
+    finished = 0
+    for t in range(steps):
+        a = (rng.uniform(-1, 1, (n, 6)) * (0.15 if t > 60 else 1.0)).astype(np.float32)  # small moves late: some envs reach step 100
+        d, _ = step_both(oracle, kind, env, orc, a, where=f"ori prefetch={prefetch} step {t}")
+        finished += d
+    assert finished > n  # every env finished at least once (truncation at the latest)
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()

@@ -122,6 +122,7 @@ struct KParams {
   int* rzero2;      // a second one
   int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
   int prefetch;     // 1: STEP resets finished envs inline from valid records; RESET files refill entries
+  int inline_ori;   // 1: STEP of UR5OriReach-v1 resets finished envs inline (its reset is one goal draw, reach.py:197-200): no RESET launch
   float neutral_ach[6];  // end-effector position + Euler angles of the neutral pose, float32 as _get_obs casts them (set at create)
 };
 __device__ __forceinline__ double& REC(const KParams& P, int slot, int f, int n) {
@@ -1164,7 +1165,24 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       B.collision[n] = coll ? 1 : 0;
       if (cfg.auto_reset && (terminated || truncated)) {
         bool consumed = false;
-        if (P.prefetch) {
+        if (KIND == URGYM_ENV_ORI && P.inline_ori) {
+          // ---- ReachOri.reset (reach.py:197-200) is a goal draw that is never rejected: done here, what env_kernel<RESET> would do
+          consumed = true;
+          for (int i = 0; i < OD; i++) B.final_observation[(size_t)n * OD + i] = row[i];
+          for (int i = 0; i < GD; i++) {
+            B.final_achieved_goal[(size_t)n * GD + i] = row[OD + i];
+            B.final_desired_goal[(size_t)n * GD + i] = row[OD + GD + i];
+          }
+          const int ecur = B.episode_id[n];
+          double g2[6] = {0, 0, 0, 0, 0, 0}, none[6] = {0, 0, 0, 0, 0, 0}, q2[6], nold[5] = {0, 0, 0, 0, 0}, nop[3] = {0, 0, 0};
+          sample_attempt<URGYM_ENV_ORI>(P, pose_slot, n, (uint32_t)ecur, 0, g2, none, none);
+          for (int i = 0; i < 6; i++) { q2[i] = cfg.neutral_q[i]; SOA(B.goal, i, n, N) = g2[i]; SOA(B.q, i, n, N) = q2[i]; }
+          B.step_count[n] = 0;
+          B.episode_id[n] = ecur + 1;
+          float ach2[6];
+          for (int i = 0; i < 6; i++) ach2[i] = P.neutral_ach[i];
+          write_row(ach2, q2, g2, none, nop, Q4{0, 0, 0, 1}, none, nold);
+        } else if (P.prefetch) {
           // ---- inline auto-reset from the prefetched record of the env's next episode (valid iff it was computed for
           // exactly this episode id): what env_kernel<RESET> would do, minus the search.
           const int ecur = B.episode_id[n], sl = ecur & 1;
@@ -1414,6 +1432,7 @@ struct Handle {
   double last_refill_us = 0.0;
   // prefetched episode records (DESIGN.md "auto-reset off the critical path")
   bool prefetch = false;
+  bool inline_ori = false;  // UR5OriReach-v1: finished envs are reset inside the step kernel (no RESET launch per step)
   float neutral_ach[6] = {0, 0, 0, 0, 0, 0};
   double* d_rec = nullptr;      // [2][REC_FIELDS][N]
   int32_t* d_reci = nullptr;    // [2][2][N]
@@ -1522,6 +1541,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.rzero2 = nullptr;
   P.fallback_on = 1;
   P.prefetch = 0;
+  P.inline_ori = h->inline_ori ? 1 : 0;
   for (int i = 0; i < 6; i++) P.neutral_ach[i] = h->neutral_ach[i];
   return P;
 }
@@ -1618,7 +1638,7 @@ int do_step(Handle* h, const float* actions, hipStream_t s) {
   int slot = time_begin(h, 0, s);
   launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
   time_end(h, slot, s);
-  if (h->cfg.auto_reset && !pf) {
+  if (h->cfg.auto_reset && !pf && !h->inline_ori) {
     slot = time_begin(h, 1, s);
     launch_mode<MODE_RESET>(h, P, nullptr, h->reset_envs, s);  // ~1 % of the envs per step: small workgroups, many CUs
     time_end(h, slot, s);
@@ -1811,6 +1831,23 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     }
     // prefetched episode records: on unless URGYM_PREFETCH=0 (then finished envs are reset by a kernel after each step)
     // (Ori's reset is a goal draw, no distance query: there the extra launches cost more than the reset kernel they replace)
+    {  // the neutral pose's end-effector frame (the first six slots of every reset observation), by the device code itself
+      double* dq = nullptr;
+      float* dout = nullptr;
+      hipError_t ne = hipMalloc((void**)&dq, sizeof(double) * 6);
+      if (ne == hipSuccess) ne = hipMalloc((void**)&dout, sizeof(float) * 6);
+      if (ne == hipSuccess) ne = hipMemcpy(dq, cfg->neutral_q, sizeof(double) * 6, hipMemcpyHostToDevice);
+      if (ne == hipSuccess) {
+        hipLaunchKernelGGL(ee_pose_kernel, dim3(1), dim3(1), 0, 0, dq, dout);
+        ne = hipMemcpy(h->neutral_ach, dout, sizeof(float) * 6, hipMemcpyDeviceToHost);
+      }
+      if (dq) hipFree(dq);
+      if (dout) hipFree(dout);
+      // UR5OriReach-v1: inline reset unless URGYM_PREFETCH=0 asks for the reset kernel (the switch of the obstacle envs, same meaning)
+      bool want_inline = cfg->env_kind == URGYM_ENV_ORI && ne == hipSuccess;
+      if (const char* ov = getenv("URGYM_PREFETCH")) want_inline = want_inline && atoi(ov) != 0;
+      h->inline_ori = want_inline;
+    }
     h->prefetch = want_prefetch;
     if (h->prefetch) {
       const size_t nn = (size_t)n;
@@ -1823,19 +1860,6 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 5);
       if (pe == hipSuccess) pe = hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * nn);
       if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 5);
-      if (pe == hipSuccess) {  // the neutral pose's end-effector frame, by the device code itself
-        double* dq = nullptr;
-        float* dout = nullptr;
-        pe = hipMalloc((void**)&dq, sizeof(double) * 6);
-        if (pe == hipSuccess) pe = hipMalloc((void**)&dout, sizeof(float) * 6);
-        if (pe == hipSuccess) pe = hipMemcpy(dq, cfg->neutral_q, sizeof(double) * 6, hipMemcpyHostToDevice);
-        if (pe == hipSuccess) {
-          hipLaunchKernelGGL(ee_pose_kernel, dim3(1), dim3(1), 0, 0, dq, dout);
-          pe = hipMemcpy(h->neutral_ach, dout, sizeof(float) * 6, hipMemcpyDeviceToHost);
-        }
-        if (dq) hipFree(dq);
-        if (dout) hipFree(dout);
-      }
       if (pe == hipSuccess) {  // lowest priority: the refill should take the slots the step kernel leaves free, not compete for them
         int least = 0, greatest = 0;
         hipDeviceGetStreamPriorityRange(&least, &greatest);
