@@ -1,19 +1,22 @@
 // urgym_hip.hip — fused UR5e reach environment kernels for MI355X (gfx950) + the C-ABI of include/urgym.h.
 //
 // One kernel template env_kernel<KIND, MODE> (MODE = STEP | RESET | REFRESH | PREFETCH); device math in urgym_device.h.
-// One workgroup = 4 waves (256 lanes) serving E <= 64 environments (E is a launch parameter, urgym_create picks it).
+// One workgroup = 4 waves (256 lanes) serving E environments (a launch parameter urgym_create picks: up to 128 for STEP, so that
+// N = 65536 is ONE round of resident workgroups; up to 64 for RESET / REFRESH, 32 for PREFETCH).
 //
-//   P1   one lane per env (STEP: on the LAST wave, while the other waves already run their queries): joint update
+//   P1   one lane per env (STEP: on the LAST wave(s), while the other waves already run their queries): joint update
 //        q += f32(f32(clip(a) * pi) * 0.1) (UR5.py:273-279), one float64 FK pass, world bounding capsules, conservative
 //        culling of the 19 table / track / self pairs of check_collision (pyb_setup.py:382-429) -> a 19-bit mask per env in
-//        LDS; the end-effector read-out (pyb_setup.py:221-253).  STEP keeps NO joint / obstacle state in LDS: any lane
-//        re-derives them from global memory (joint_of_step, obstacle_of_step).
+//        LDS; the end-effector read-out (pyb_setup.py:221-253); the env's set-up cache (sin / cos of the joints, advanced
+//        obstacle pose) in a global scratch.  STEP keeps NO joint / obstacle state in LDS: a lane re-derives them from global
+//        memory (joint_of_step, obstacle_of_step) until P1 has published, and reads the cache afterwards.
 //   pool the closest-distance work of the workgroup: 5 E obstacle "tickets" (exact distance hull(link) <-> cylinder,
 //        pyb_setup.py:439-456; 15 E with URGYM_LINK_DIST_WORKBENCH: table and track too) + the set bits of the pair masks
 //        (boolean "closer than the margin?" queries).  Every lane advances ITS query by one GJK iteration per loop trip
 //        through one inlined, resumable GJK body (gjk_begin / gjk_iterate); idle lanes draw the next item together.
 //   EPA  the (rare) obstacle queries whose cores overlap and whose distance is consumed: penetration depth by an expanding
-//        polytope, one wave per query, faces spread over the lanes (pyb_setup.py:452 stores a negative contact distance).
+//        polytope, one wave per query, faces spread over the lanes (pyb_setup.py:452 stores a negative contact distance);
+//        served by waves that have left the pool while the others still iterate.
 //   P4   one lane per env: pose distances, success / collision / reward (reach.py:221-236, 356-374, 764-785), lagged
 //        link_dist, state write-back; a finished env is reset inline from its prefetched episode record or appended to the
 //        done list; observation rows -> LDS -> coalesced stores.
@@ -103,7 +106,7 @@ struct KParams {
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
   int copy_final;   // RESET: 1 = auto-reset (keep the step's reward/flags, save the terminal observation)
-  int envs;         // envs per workgroup, 1 .. MAX_ENVS (chosen per launch: see urgym_create / do_step)
+  int envs;         // envs per workgroup (chosen per launch: see urgym_create / do_step / launch_mode)
   int big_blocks;   // STEP only: the first big_blocks workgroups serve `envs` envs each, the rest `envs_tail` (two-tier launch
   int envs_tail;    // geometry: the last round of workgroups is made of smaller, shorter ones; 0 = uniform)
   // prefetched episode records (null / 0 when the feature is off)
@@ -515,7 +518,7 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 // collision checks on can never consume a penetration depth, and its kernel stays free of that code's registers and scratch)
 template <int KIND, int MODE, bool WITH_EPA>
 __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
-  // per-env slots (E = P.envs envs per workgroup, <= MAX_ENVS) ...
+  // per-env slots (E envs per workgroup, <= ME) ...
   // PREFETCH workgroups run UNDER a step kernel: with at most 32 envs and no joint array they need < 55 KB and share a CU with
   // two step workgroups instead of displacing both
   constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // array is indexed dynamically (that would live in scratch)
   constexpr int OD = (KIND == URGYM_ENV_ORI) ? 18 : ((KIND == URGYM_ENV_OBS) ? 26 : ((KIND == URGYM_ENV_STA) ? 29 : 35));
   constexpr int GD = (KIND == URGYM_ENV_OBS) ? 3 : 6;
-  // envs of this workgroup (1 .. MAX_ENVS) and the index of its first env / list entry.  STEP launches may be two-tiered.
+  // envs of this workgroup (1 .. ME) and the index of its first env / list entry.  STEP launches may be two-tiered.
   const bool tail_block = (MODE == MODE_STEP) && P.envs_tail > 0 && (int)blockIdx.x >= P.big_blocks;
   const int E = tail_block ? P.envs_tail : P.envs;
   const int first = tail_block ? P.big_blocks * P.envs + ((int)blockIdx.x - P.big_blocks) * P.envs_tail : (int)blockIdx.x * P.envs;
