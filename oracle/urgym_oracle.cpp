@@ -6,14 +6,19 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
  * (ur_gym_amd/) never does.
  *
- * PARITY STATUS: **parity unpinned at the pybullet boundary.**  The arithmetic of the reference lives in
- * third-party pybullet (Bullet3 C++; setup.py:22, version unpinned), scipy and numpy.  pybullet is not
- * installed/installable here and the reference ships no tests or golden vectors.  What IS
- * pinned: utils.distance / utils.angular_distance against fixtures generated from the reference's own
- * UR_gym/utils.py (tests/golden/utils_golden.json), and the forward kinematics against an independent scipy
- * evaluation of the URDF chain.  Everything tagged [BULLET] below restates the published bullet3 algorithm
- * (btGjkPairDetector, btVoronoiSimplexSolver, btMultiBody::stepPositionsMultiDof, pybullet.c quaternion
- * helpers) from its call sites in UR_gym/pyb_setup.py.
+ * PARITY STATUS: pinned at the pybullet boundary by outputs of the reference's own PyBullet environments, as far as the
+ * reference holds any.  pybullet is not installed/installable here and the reference ships no tests, but its SAC checkpoints
+ * carry two consecutive observations each as plain text in their JSON (tests/golden/reference_observations.json, generator
+ * next to it).  Against them (tests/test_reference_pins.py): forward kinematics + Bullet's Euler read-out (8 samples,
+ * <= 7e-7 m), getClosestPoints link distances incl. collision margins (25 values, <= 1e-7 m), the moving obstacle's
+ * integration (3e-8 m) and one whole step() per env.  utils.distance / utils.angular_distance are pinned by fixtures generated
+ * from the reference's own UR_gym/utils.py (tests/golden/utils_golden.json); the closed-loop replay of the four shipped actors
+ * reproduces the per-trial statistics the reference ships (tests/test_closed_loop.py).
+ * STILL UNPINNED (no reference value exists): the path-dependent last digits of Bullet's GJK at degenerate simplices, hull <->
+ * hull self-collision verdicts, the exact value of a penetration depth (Bullet's own EPA accuracy is 1e-4), the Euler branches at
+ * |sin pitch| >= 0.99999, physics side effects of stepSimulation on the teleported arm.  Everything tagged [BULLET] below restates
+ * the published bullet3 algorithm (btGjkPairDetector, btVoronoiSimplexSolver, btMultiBody, pybullet.c quaternion helpers) from its
+ * call sites in UR_gym/pyb_setup.py (pybullet is a dependency of the reference, setup.py:22, version unpinned).
  *
  * Every function cites the reference file:line (under /root/reference) it follows.
  */

@@ -7,7 +7,8 @@ What pins the oracle:
   * Bullet quaternion/Euler conventions: scipy Rotation                                                 -> 1e-12
   * closest distances (GJK restatement): analytic cases and an independent constrained optimiser         -> 1e-6
   * task semantics (lagged link_dist, early returns, obstacle motion, truncation, reset rules): by construction
-At the pybullet boundary itself parity is unpinned (no pybullet here, no reference fixtures) — see DESIGN.md.
+  * at the pybullet boundary itself: tests/test_reference_pins.py (observations of the reference's own PyBullet envs)
+What no reference value exists for is listed in DESIGN.md section 3.
 """
 import json
 import os

@@ -6,6 +6,8 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > $OUT/gpu_tests.log 2>&1; echo "exit $?" >> $OUT/gpu_tests.log
+grep -E "passed|failed" $OUT/gpu_tests.log | tail -2
 : > $OUT/speed.jsonl
 one() {
   env "$@" timeout -k 10 120 python bench.py --no-cpu-baseline --steps 200 --warmup 20 2>/dev/null | python -c "
@@ -14,7 +16,7 @@ b = json.loads(sys.stdin.readline())
 print(json.dumps({'cfg': '$*', 'value': b['value'], 'ms_per_step': b['ms_per_step'], 'kernel_us': b['roofline']['kernel_us']}))" >> $OUT/speed.jsonl
 }
 pushd /tmp > /dev/null; export TMPDIR=/tmp
-for V in "URGYM_STEP_ENVS=91 URGYM_SETUP_CACHE=1" "URGYM_STEP_ENVS=96 URGYM_SETUP_CACHE=1" "URGYM_STEP_ENVS=91 URGYM_SETUP_CACHE=0" "URGYM_STEP_ENVS=96 URGYM_SETUP_CACHE=0" "URGYM_STEP_ENVS=48 URGYM_SETUP_CACHE=0"; do
+for V in "URGYM_SETUP_CACHE=1" "URGYM_SETUP_CACHE=0" "URGYM_STEP_ENVS=96 URGYM_SETUP_CACHE=1" "URGYM_STEP_ENVS=96 URGYM_SETUP_CACHE=0"; do
   tag=$(echo $V | tr ' =' '__')
   (cd $R; one $V)
   for C in FETCH_SIZE WRITE_SIZE; do

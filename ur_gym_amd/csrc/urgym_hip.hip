@@ -555,9 +555,18 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   constexpr int OD = (KIND == URGYM_ENV_ORI) ? 18 : ((KIND == URGYM_ENV_OBS) ? 26 : ((KIND == URGYM_ENV_STA) ? 29 : 35));
   constexpr int GD = (KIND == URGYM_ENV_OBS) ? 3 : 6;
   // envs of this workgroup (1 .. ME) and the index of its first env / list entry.  STEP launches may be two-tiered.
-  const bool tail_block = (MODE == MODE_STEP) && P.envs_tail > 0 && (int)blockIdx.x >= P.big_blocks;
+  // XCD-aware workgroup -> env-range mapping (STEP, uniform geometry): the hardware deals workgroups round-robin over the 8 XCDs
+  // (workgroup b runs on XCD b % 8), each with its own L2.  Workgroup b therefore serves env range vb = start(b % 8) + b / 8, where
+  // XCD x owns the contiguous block of ranges [start(x), start(x + 1)): neighbouring ranges -- which share the 128-byte lines at
+  // the ends of their runs in the float64 state arrays -- then meet in ONE L2 instead of being fetched by two.
+  int vb = (int)blockIdx.x;
+  if (MODE == MODE_STEP && P.envs_tail == 0) {
+    const int nb = (int)gridDim.x, x = vb & 7, per = nb >> 3, rem = nb & 7;
+    vb = x * per + (x < rem ? x : rem) + (vb >> 3);
+  }
+  const bool tail_block = (MODE == MODE_STEP) && P.envs_tail > 0 && vb >= P.big_blocks;
   const int E = tail_block ? P.envs_tail : P.envs;
-  const int first = tail_block ? P.big_blocks * P.envs + ((int)blockIdx.x - P.big_blocks) * P.envs_tail : (int)blockIdx.x * P.envs;
+  const int first = tail_block ? P.big_blocks * P.envs + (vb - P.big_blocks) * P.envs_tail : vb * P.envs;
   const int G = (E + GROUP - 1) / GROUP;     // waves that run the per-env phases
   constexpr bool HAS_OBST = (KIND != URGYM_ENV_ORI);
   constexpr int COLL_BIT = 1 << 30;
