@@ -254,7 +254,15 @@ __device__ __forceinline__ int dirmap_cell(D3 d) {  // float32 is plenty: any ce
 
 // d . v evaluated exactly like the oracle's scan ((x*dx + y*dy) + z*dz, no fused ops) so that near-tied vertices are
 // ranked identically on both sides.
+#if defined(URGYM_HOST_HARNESS)
 __device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) { return (x * d.x + y * d.y) + z * d.z; }
+#else
+// (explicitly rounded products and sums: this ranking must not be contracted into fused operations whatever the build's
+//  -ffp-contract setting is, or near-tied vertices could be ranked differently from the oracle's scan)
+__device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) {
+  return __dadd_rn(__dadd_rn(__dmul_rn(x, d.x), __dmul_rn(y, d.y)), __dmul_rn(z, d.z));
+}
+#endif
 
 // branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together).  Only the
 // value and the id are tracked; the winner's coordinates are fetched once, when the climb has ended.
