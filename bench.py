@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--no-collision", action="store_true",
                     help="check_collision=0: BASELINE.json configs[1] 'FK + pose-distance reward kernel only' (not the reference's step)")
     ap.add_argument("--rollout", action="store_true", help="enqueue all K steps through urgym_rollout (no Python per step)")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="diagnostic: no HIP events around the kernels (roofline.achieved is then 0)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -226,7 +227,7 @@ def main():
     if args.rollout and gathered is None:  # resident before the timed region, like the per-step action batches
         rollout_actions = torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)])
     torch.cuda.synchronize(dev)
-    env.enable_timing(True)
+    env.enable_timing(not args.no_kernel_timing)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -241,7 +242,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    step_us, reset_us, launches = env.query_timing()
+    step_us, reset_us, launches = (0.0, 0.0, 0) if args.no_kernel_timing else env.query_timing()
     env.enable_timing(False)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)

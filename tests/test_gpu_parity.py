@@ -817,3 +817,38 @@ def test_ori_auto_reset_paths_match_oracle(oracle, monkeypatch, prefetch):
     assert finished > n  # every env finished at least once (truncation at the latest)
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
     env.close()
+
+
+def test_refresh_with_a_penetrating_obstacle_reports_the_depth(oracle):
+    """set_goal_and_obstacle (reach.py:328-335) with the obstacle put INTO the arm: link_dist of the touched links is the negative
+    penetration depth (EPA in the REFRESH kernel), collision is flagged, and the next step goes on from there like the oracle's."""
+    n = 40
+    env = make_vec("UR5ObsReach-v1", num_envs=n, seed=7, auto_reset=False)
+    orc = oracle.OracleEnv(_abi.ENV_OBS, n, auto_reset=0)
+    env.reset(seed=7)
+    orc.reset(seed=7)
+    _, t = oracle.fk(np.array([0.0, -1.5708, 0.0, -1.5708, 0.0, 0.0]))  # neutral pose: link frames
+    rng = np.random.default_rng(7)
+    ids = np.arange(0, n, 2)
+    data = []
+    for k, i in enumerate(ids):
+        link = 2 + k % 5
+        centre = 0.5 * (t[link] + t[min(link + 1, 6)]) + rng.normal(0, 0.01, 3)   # somewhere inside link `link`
+        data.append(np.r_[rng.uniform([0.3, -0.5, -0.1], [0.75, 0.5, 0.2]), centre, rng.uniform(-2.6, 2.6, 2), 0.0])
+    data = np.array(data)
+    orc.buf["goal"][:3, ids] = data[:, :3].T
+    orc.buf["obst_start"][:, ids] = data[:, 3:9].T
+    mask = np.zeros(n, np.uint8)
+    mask[ids] = 1
+    orc.refresh(mask)
+    env.set_goal_and_obstacle(ids, data)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    assert (orc.buf["link_dist"][:, ids] < -0.002).any(axis=0).sum() >= len(ids) // 2      # real penetration depths ...
+    assert np.abs(st["link_dist"] - orc.buf["link_dist"]).max() < 1e-8                       # ... equal on both sides
+    assert np.array_equal(np_(env.buf["collision"]), orc.buf["collision"]) and orc.buf["collision"][ids].all()
+    assert obs_diff(_abi.ENV_OBS, np_(env.buf["observation"]), orc.buf["observation"]) < OBS_TOL
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    a = rng.uniform(-0.2, 0.2, (n, 6)).astype(np.float32)
+    step_both(oracle, _abi.ENV_OBS, env, orc, a, where="after penetrating refresh")
+    env.close()
