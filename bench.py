@@ -227,7 +227,7 @@ def main():
     if args.rollout and gathered is None:  # resident before the timed region, like the per-step action batches
         rollout_actions = torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)])
     torch.cuda.synchronize(dev)
-    env.enable_timing(not args.no_kernel_timing)
+    env.enable_timing(not args.no_kernel_timing, every=8)  # HIP events around every 8th step launch (an event pair costs the stream ~6 us)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -281,7 +281,7 @@ def main():
                          "traffic_source": "profiles/r2/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
                          "valu_issue": valu,  # what really bounds the kernel: float64 VALU issue + the latency of the GJK chains
                          "algorithmic_bytes_per_launch": algo,
-                         "kernel": "env_kernel<Dyn,STEP>" if args.env == "UR5DynReach-v1" else "env_kernel<STEP>",
+                         "kernel": "env_step_fused<Dyn> (STEP workgroups + the refill of the previous step's episode records)" if args.env == "UR5DynReach-v1" else "step launch",
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
                          "overlapped_refill_kernel_us": getattr(env, "last_refill_us", 0.0),
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],

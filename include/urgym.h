@@ -208,8 +208,9 @@ int urgym_probe_closest(void* handle, int count, const int* type_a, const double
  * device code directly (tests/test_gpu_parity.py). */
 int urgym_probe_pose_distance(void* handle, int count, const double* a6, const double* b6, double* out2, void* stream);
 
-/* Average device time (microseconds) of the step kernel over the calls since the last query, measured with
- * hipEvents on the launch stream; returns <0 if timing was not enabled. */
+/* Average device time (microseconds) of the step launch over the calls since the last query, measured with hipEvents on the
+ * launch stream; returns <0 if timing was not enabled.  enable = k > 1 times every k-th step only: a pair of events costs the
+ * stream about 6 us per step, i.e. measuring every launch slows the thing measured by ~3 % (bench.py samples every 8th). */
 int urgym_enable_timing(void* handle, int enable);
 int urgym_query_timing(void* handle, double* step_kernel_us, double* reset_kernel_us, int* launches);
 

@@ -6,9 +6,13 @@ d = sys.argv[1]
 out = {}
 for f in glob.glob(f"{d}/*/*/*counter_collection.csv"):
     df = pd.read_csv(f)
-    df = df[df.Kernel_Name.str.contains("env_kernel")]
+    df = df[df.Kernel_Name.str.contains("env_kernel|env_step_fused")]
     if df.empty: continue
-    df["kernel"] = df.Kernel_Name.str.extract(r"(env_kernel<\d, \d)")[0] + ">"  # key: env_kernel<KIND, MODE> (the EPA flag is dropped)
+    # key: env_kernel<KIND, MODE> (the EPA flag is dropped); the fused step launch (STEP workgroups + the refill of the previous
+    # step's episode records) is filed as the step kernel of its env kind
+    k1 = df.Kernel_Name.str.extract(r"(env_kernel<\d, \d)")[0] + ">"
+    k2 = "env_kernel<" + df.Kernel_Name.str.extract(r"env_step_fused<(\d)")[0] + ", 0>"
+    df["kernel"] = k1.where(k1.notna(), k2)
     g = df.groupby(["kernel", "Counter_Name"]).Counter_Value.mean().unstack()
     for k, row in g.iterrows():
         out.setdefault(k, {}).update({c: float(v) for c, v in row.items()})
@@ -29,9 +33,10 @@ for k, v in out.items():
     if "TCC_HIT_sum" in v: v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
 for f in glob.glob(f"{d}/trace/*/*kernel_stats.csv"):
     ks = pd.read_csv(f)
-    ks = ks[ks.Name.str.contains("env_kernel")]
+    ks = ks[ks.Name.str.contains("env_kernel|env_step_fused")]
     for _, r in ks.iterrows():
         import re
-        k = re.search(r"(env_kernel<\d, \d)", r.Name).group(1) + ">"
+        m = re.search(r"(env_kernel<\d, \d)", r.Name)
+        k = (m.group(1) + ">") if m else "env_kernel<" + re.search(r"env_step_fused<(\d)", r.Name).group(1) + ", 0>"
         out.setdefault(k, {}).update({"calls": int(r.Calls), "avg_ns": float(r.AverageNs), "min_ns": float(r.MinNs), "max_ns": float(r.MaxNs)})
 print(json.dumps(out, indent=1))

@@ -505,8 +505,8 @@ constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 12;
 __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP(k, v)                                                                                         \
   do {                                                                                                      \
-    if (MODE == URGYM_STAMP_MODE && lane == 0 && blockIdx.x < STAMP_BLOCKS)                                        \
-      g_stamps[((size_t)blockIdx.x * WAVES + wv) * STAMP_SLOTS + (k)] = (unsigned long long)(v);            \
+    if (MODE == URGYM_STAMP_MODE && lane == 0 && bidx < STAMP_BLOCKS)                                              \
+      g_stamps[((size_t)bidx * WAVES + wv) * STAMP_SLOTS + (k)] = (unsigned long long)(v);                  \
   } while (0)
 #define STAMP_TIME(k) STAMP(k, __builtin_amdgcn_s_memtime())
 #else
@@ -514,35 +514,54 @@ __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP_TIME(k) do {} while (0)
 #endif
 
-// WITH_EPA: compiled with the penetration-depth phase (the host picks the instance: a STEP launch of Dyn / Sta with the
-// collision checks on can never consume a penetration depth, and its kernel stays free of that code's registers and scratch)
-template <int KIND, int MODE, bool WITH_EPA>
-__global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
+// LDS of one workgroup, per launch mode.  A struct (not function-local __shared__ arrays) so that the fused step launch can
+// overlay the layouts of its two kinds of workgroups (STEP and PREFETCH) in one allocation.
+template <int MODE>
+struct EnvLds {
   // per-env slots (E envs per workgroup, <= ME) ...
-  // PREFETCH workgroups run UNDER a step kernel: with at most 32 envs and no joint array they need < 55 KB and share a CU with
-  // two step workgroups instead of displacing both
-  constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
-  constexpr bool LDS_Q = (MODE == MODE_REFRESH);  // RESET / PREFETCH: the joints are the neutral pose, a constant
+  // PREFETCH workgroups run beside STEP workgroups: with at most 32 envs and no joint array they need < 53 KB as well
+  static constexpr int ME = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
+  static constexpr bool LDS_Q = (MODE == MODE_REFRESH);  // RESET / PREFETCH: the joints are the neutral pose, a constant
   // link distances of the workgroup's envs: LDS, except STEP (global scratch [5][N], rows of consecutive envs: coalesced; the
   // cells are written by query lanes and read by the P4 lanes of the SAME workgroup after a barrier)
-  constexpr bool DIST_LDS = (MODE != MODE_STEP);
-  __shared__ double s_dist[5][DIST_LDS ? ME : 1];
+  static constexpr bool DIST_LDS = (MODE != MODE_STEP);
   // STEP launches re-derive the joints and the obstacle pose from global memory wherever they are needed (joint_of_step,
-  // obstacle_of_step): 6.5 KB less LDS, which is what lets a third workgroup stay resident on the CU.  RESET / REFRESH
-  // launches hand them from the sampling lane to the query lanes through LDS (global memory written by this launch is
-  // not safely readable through the CU's L1).
-  constexpr bool LDS_STATE = (MODE != MODE_STEP);
-  __shared__ double s_q[LDS_Q ? 6 : 1][LDS_Q ? ME : 1];                    // joint vector
-  __shared__ double s_obst[LDS_STATE ? 7 : 1][LDS_STATE ? ME : 1];         // obstacle position + quaternion
-  __shared__ uint32_t s_pairs[ME];         // culling survivors: one bit per table / track / self pair (PAIR_* below)
-  __shared__ int s_flags[ME];              // status bits | COLL_BIT
-  __shared__ int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
-  __shared__ int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
-  __shared__ int s_p1done;                 // STEP: the per-env phase has published its pair masks
-  __shared__ int s_left;                   // waves that have left the work pool (the EPA service below polls it)
-  __shared__ int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
+  // obstacle_of_step, later the set-up cache): 6.5 KB less LDS, which is what lets a third workgroup stay resident on the CU.
+  // RESET / REFRESH launches hand them from the sampling lane to the query lanes through LDS.
+  static constexpr bool LDS_STATE = (MODE != MODE_STEP);
+  double s_dist[5][DIST_LDS ? ME : 1];
+  double s_q[LDS_Q ? 6 : 1][LDS_Q ? ME : 1];                    // joint vector
+  double s_obst[LDS_STATE ? 7 : 1][LDS_STATE ? ME : 1];         // obstacle position + quaternion
+  uint32_t s_pairs[ME];         // culling survivors: one bit per table / track / self pair (PAIR_* below)
+  int s_flags[ME];              // status bits | COLL_BIT
+  int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
+  int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
+  int s_p1done;                 // STEP: the per-env phase has published its pair masks
+  int s_left;                   // waves that have left the work pool (the EPA service polls it)
+  int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
-  __shared__ double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
+  double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
+};
+
+// WITH_EPA: compiled with the penetration-depth phase (the host picks the instance: a STEP launch of Dyn / Sta with the
+// collision checks on can never consume a penetration depth, and its kernel stays free of that code's registers and scratch).
+// bidx / nblk: index of this workgroup among those of its kind in the launch, and their number.
+template <int KIND, int MODE, bool WITH_EPA>
+__device__ __forceinline__ void env_body(const KParams& P, const float* __restrict__ actions, EnvLds<MODE>& L, const int bidx, const int nblk) {
+  constexpr int ME = EnvLds<MODE>::ME;
+  constexpr bool LDS_Q = EnvLds<MODE>::LDS_Q, DIST_LDS = EnvLds<MODE>::DIST_LDS, LDS_STATE = EnvLds<MODE>::LDS_STATE;
+  auto& s_dist = L.s_dist;
+  auto& s_q = L.s_q;
+  auto& s_obst = L.s_obst;
+  auto& s_pairs = L.s_pairs;
+  auto& s_flags = L.s_flags;
+  auto& s_env = L.s_env;
+  int& s_ticket = L.s_ticket;
+  int& s_pending = L.s_pending;
+  int& s_p1done = L.s_p1done;
+  int& s_left = L.s_left;
+  auto& s_key = L.s_key;
+  auto& s_pose = L.s_pose;
 
   const urgym_config& cfg = P.cfg;
   const urgym_buffers& B = P.buf;
@@ -559,9 +578,9 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
   // (workgroup b runs on XCD b % 8), each with its own L2.  Workgroup b therefore serves env range vb = start(b % 8) + b / 8, where
   // XCD x owns the contiguous block of ranges [start(x), start(x + 1)): neighbouring ranges -- which share the 128-byte lines at
   // the ends of their runs in the float64 state arrays -- then meet in ONE L2 instead of being fetched by two.
-  int vb = (int)blockIdx.x;
+  int vb = bidx;
   if (MODE == MODE_STEP && P.envs_tail == 0) {
-    const int nb = (int)gridDim.x, x = vb & 7, per = nb >> 3, rem = nb & 7;
+    const int nb = nblk, x = vb & 7, per = nb >> 3, rem = nb & 7;
     vb = x * per + (x < rem ? x : rem) + (vb >> 3);
   }
   const bool tail_block = (MODE == MODE_STEP) && P.envs_tail > 0 && vb >= P.big_blocks;
@@ -584,7 +603,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
     return DIST_LDS ? (double*)&s_dist[i][DIST_LDS ? e : 0] : &P.ld_scratch[(size_t)i * N + first + e];
   };
 
-  if (blockIdx.x == 0 && tid == 0) {  // (before any early exit)
+  if (bidx == 0 && tid == 0) {  // (before any early exit)
     if (P.rzero) *P.rzero = 0;
     if (P.rzero2) *P.rzero2 = 0;
   }
@@ -1296,7 +1315,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       B.achieved_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + (i % GD)];
       B.desired_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + GD + (i % GD)];
     }
-    if (blockIdx.x == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
+    if (bidx == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
   } else if (MODE != MODE_PREFETCH) {
     const int cnt = min(E, list_count - first);
     for (int i = tid; i < cnt * OD; i += THREADS) {
@@ -1313,6 +1332,27 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
       B.desired_goal[(size_t)ne * GD + (i % GD)] = s_out[e * 47 + OD + GD + (i % GD)];
     }
   }
+}
+
+template <int KIND, int MODE, bool WITH_EPA>
+__global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
+  __shared__ EnvLds<MODE> lds;
+  env_body<KIND, MODE, WITH_EPA>(P, actions, lds, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The steady-state step launch: `step_blocks` STEP workgroups (parameters Ps) followed by the PREFETCH workgroups (Pr) that refill
+// the episode records consumed by the PREVIOUS step.  One launch instead of a step kernel on the caller's stream plus a refill
+// kernel on a side stream with two events and two stream waits per step; the refill workgroups come last in the grid, so they take
+// the slots the step workgroups free in the tail of the launch.  The two kinds never touch the same data (the refill writes record
+// slots the concurrent step cannot read -- episode parity -- and reads nothing the step writes: the episode id travels in its list).
+template <int KIND, bool WITH_EPA>
+__global__ void __launch_bounds__(THREADS, 3) env_step_fused(const KParams Ps, const KParams Pr, const float* __restrict__ actions, const int step_blocks) {
+  __shared__ union FusedLds {
+    EnvLds<MODE_STEP> step;
+    EnvLds<MODE_PREFETCH> refill;
+  } lds;
+  if ((int)blockIdx.x < step_blocks) env_body<KIND, MODE_STEP, WITH_EPA>(Ps, actions, lds.step, (int)blockIdx.x, step_blocks);
+  else env_body<KIND, MODE_PREFETCH, true>(Pr, nullptr, lds.refill, (int)blockIdx.x - step_blocks, (int)gridDim.x - step_blocks);
 }
 
 // end-effector pose of a joint vector exactly as P4 derives it (urgym_create evaluates the neutral pose once)
@@ -1438,6 +1478,8 @@ struct Handle {
   char err[512] = {0};
   // timing
   bool timing = false;
+  int timing_every = 1;   // time every k-th step (an event pair costs the stream ~6 us: sampling keeps the measurement out of the measured)
+  long timing_tick = 0;
   std::vector<hipEvent_t> ev;  // pairs: [2i] start, [2i+1] stop ; kind in ev_kind
   std::vector<int> ev_kind;    // 0 = step kernel, 1 = reset kernel(s) on the caller's stream, 2 = overlapped refill
   size_t ev_used = 0;
@@ -1451,9 +1493,6 @@ struct Handle {
   int2* d_rl[4] = {nullptr, nullptr, nullptr, nullptr};  // refill lists: three rotating asynchronous ones, one synchronous (index 3)
   int rl_cap[4] = {0, 0, 0, 0};
   int* d_rcount = nullptr;      // their counters
-  hipStream_t rs = nullptr;     // side stream of the asynchronous refills
-  hipEvent_t ev_step = nullptr, ev_refill = nullptr;
-  bool refill_pending = false;
   int parity = 0;
   uint64_t rec_seed = 0;
   bool rec_seed_valid = false;
@@ -1587,8 +1626,39 @@ void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream
   }
 }
 
+// The steady-state step of the obstacle envs: STEP workgroups + the PREFETCH workgroups that refill what the previous step consumed
+// (env_step_fused).  Ps / Pr: parameters of the two parts.
+void launch_fused(Handle* h, KParams Ps, KParams Pr, const float* actions, hipStream_t s) {
+  const int envs = h->step_envs < 1 ? 1 : (h->step_envs > STEP_MAX_ENVS ? STEP_MAX_ENVS : h->step_envs);
+  const long n = h->cfg.num_envs;
+  Ps.envs = envs;
+  long step_blocks = (n + envs - 1) / envs;
+  if (h->tail_envs > 0 && h->big_blocks > 0 && (long)h->big_blocks * envs < n) {
+    Ps.big_blocks = h->big_blocks;
+    Ps.envs_tail = h->tail_envs;
+    step_blocks = h->big_blocks + (n - (long)h->big_blocks * envs + h->tail_envs - 1) / h->tail_envs;
+  }
+  Pr.envs = PREFETCH_MAX_ENVS;
+  const long refill_blocks = ((long)Pr.rcap + PREFETCH_MAX_ENVS - 1) / PREFETCH_MAX_ENVS;  // an upper bound: most exit at once
+  dim3 grid((unsigned)(step_blocks + refill_blocks)), block(THREADS);
+  const bool epa = !h->cfg.check_collision;  // (which STEP launches can consume a penetration depth: see need_epa in the kernel)
+  const int sb = (int)step_blocks;
+  switch (h->cfg.env_kind) {
+    case URGYM_ENV_OBS: hipLaunchKernelGGL((env_step_fused<URGYM_ENV_OBS, true>), grid, block, 0, s, Ps, Pr, actions, sb); break;
+    case URGYM_ENV_STA:
+      if (epa) hipLaunchKernelGGL((env_step_fused<URGYM_ENV_STA, true>), grid, block, 0, s, Ps, Pr, actions, sb);
+      else hipLaunchKernelGGL((env_step_fused<URGYM_ENV_STA, false>), grid, block, 0, s, Ps, Pr, actions, sb);
+      break;
+    default:
+      if (epa) hipLaunchKernelGGL((env_step_fused<URGYM_ENV_DYN, true>), grid, block, 0, s, Ps, Pr, actions, sb);
+      else hipLaunchKernelGGL((env_step_fused<URGYM_ENV_DYN, false>), grid, block, 0, s, Ps, Pr, actions, sb);
+      break;
+  }
+}
+
 int time_begin(Handle* h, int kind, hipStream_t s) {
   if (!h->timing || h->ev_used >= 65536) return -1;
+  if (kind == 0 && (h->timing_tick++ % h->timing_every) != 0) return -1;
   if (h->ev_used + 2 > h->ev.size()) {
     for (int i = 0; i < 2; i++) {
       hipEvent_t e;
@@ -1614,9 +1684,6 @@ int check_bound(Handle* h) {
 }
 
 void release_prefetch(Handle* h) {
-  if (h->rs) { hipStreamSynchronize(h->rs); hipStreamDestroy(h->rs); h->rs = nullptr; }
-  if (h->ev_step) { hipEventDestroy(h->ev_step); h->ev_step = nullptr; }
-  if (h->ev_refill) { hipEventDestroy(h->ev_refill); h->ev_refill = nullptr; }
   if (h->d_rec) { hipFree(h->d_rec); h->d_rec = nullptr; }
   if (h->d_reci) { hipFree(h->d_reci); h->d_reci = nullptr; }
   for (int i = 0; i < 4; i++)
@@ -1635,57 +1702,48 @@ void use_list(Handle* h, KParams& P, int which) {
 int do_step(Handle* h, const float* actions, hipStream_t s) {
   KParams P = make_params(h, 1);
   const bool pf = h->prefetch && h->cfg.auto_reset;
-  // Three asynchronous refill lists rotate: step t appends the record slots it consumed to list t % 3 and refill t (side
-  // stream, under step t + 1) reads it.  List (t + 1) % 3 was last read by refill t - 2, which is complete when step kernel t
-  // runs (this stream waited for it during step t - 1, below), so step kernel t itself arms that counter for step t + 1:
-  // no launch and no memset is needed just to recycle a list.
-  const int cur = h->parity, nxt = (cur + 1) % 3;
-  const bool dirty = pf && h->dirty_steps > 0;
-  if (pf) {
+  int slot;
+  if (!pf) {
+    slot = time_begin(h, 0, s);
+    launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
+    time_end(h, slot, s);
+    if (h->cfg.auto_reset && !h->inline_ori) {
+      slot = time_begin(h, 1, s);
+      launch_mode<MODE_RESET>(h, P, nullptr, h->reset_envs, s);  // ~1 % of the envs per step: small workgroups, many CUs
+      time_end(h, slot, s);
+    }
+  } else {
+    // Finished envs are reset inline from their prefetched episode records, and the record slots a step consumes are refilled by
+    // PREFETCH workgroups that ride in the NEXT step's launch.  Three refill lists rotate: the STEP part of launch t appends to list
+    // t % 3, the PREFETCH part of launch t + 1 reads it, and the STEP part of launch t + 2 re-arms it (its reader belongs to a
+    // launch that has completed by then) -- no extra launch, memset, event or second stream.  A record consumed at step t is
+    // whole again when launch t + 1 ends, i.e. before step t + 2 could need it; at step t + 1 the env uses its other slot.
+    const int cur = h->parity, nxt = (cur + 1) % 3, prv = (cur + 2) % 3;
+    const bool dirty = h->dirty_steps > 0;
     use_list(h, P, cur);
     P.rzero = h->d_rcount + nxt;
     P.rzero2 = dirty ? h->d_rcount + 3 : nullptr;  // the synchronous list of this step's fallback launches
     P.fallback_on = dirty ? 1 : 0;
-  }
-  int slot = time_begin(h, 0, s);
-  launch_mode<MODE_STEP>(h, P, actions, h->step_envs, s);
-  time_end(h, slot, s);
-  if (h->cfg.auto_reset && !pf && !h->inline_ori) {
-    slot = time_begin(h, 1, s);
-    launch_mode<MODE_RESET>(h, P, nullptr, h->reset_envs, s);  // ~1 % of the envs per step: small workgroups, many CUs
+    KParams Pr = P;
+    use_list(h, Pr, prv);
+    Pr.rzero = Pr.rzero2 = nullptr;
+    slot = time_begin(h, 0, s);
+    launch_fused(h, P, Pr, actions, s);
     time_end(h, slot, s);
-  }
-  if (pf) {
-    // Finished envs were reset inline from their prefetched records.  In steady state every record is valid (an env's two slots
-    // hold its next two episodes, and a consumed slot is refilled before the env can need it again), so nothing else has to run
-    // on this stream.  Only while records may be stale (h->dirty_steps > 0: first use, a new binding, urgym_invalidate_records)
-    // does the step carry the fallback: the RESET kernel for envs that found no valid record, then PREFETCH for their next two
-    // episodes -- unbounded, so that an env that fell back comes out clean.
-    // The refill of the PREVIOUS step ran under this step's kernel; it must be complete before a record is rewritten by the
-    // fallback, before the next step kernel can need a record it wrote, and before that kernel re-arms its list.
-    if (h->refill_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_refill, 0));
+    // In steady state every record is valid (an env's two slots hold its next two episodes, and a consumed slot is refilled before
+    // the env can need it again).  Only while records may be stale (h->dirty_steps > 0: first use, a new binding,
+    // urgym_invalidate_records) does the step carry the fallback: the RESET kernel for envs that found no valid record, then
+    // PREFETCH for their next two episodes -- unbounded, so that an env that fell back comes out clean.
     if (dirty) {
       slot = time_begin(h, 1, s);
-      KParams Pr = P;
-      use_list(h, Pr, 3);
-      Pr.rzero = Pr.rzero2 = nullptr;
-      launch_mode<MODE_RESET>(h, Pr, nullptr, GROUP, s);
-      launch_mode<MODE_PREFETCH>(h, Pr, nullptr, 8, s, h->rl_cap[3]);
+      KParams Pf = P;
+      use_list(h, Pf, 3);
+      Pf.rzero = Pf.rzero2 = nullptr;
+      launch_mode<MODE_RESET>(h, Pf, nullptr, GROUP, s);
+      launch_mode<MODE_PREFETCH>(h, Pf, nullptr, 8, s, h->rl_cap[3]);
       time_end(h, slot, s);
       h->dirty_steps--;
     }
-    // the refill of the slots consumed in this step runs on the side stream, under the next step's kernel
-    HIP_TRY(h, hipEventRecord(h->ev_step, s));
-    HIP_TRY(h, hipStreamWaitEvent(h->rs, h->ev_step, 0));
-    KParams Pa = P;
-    use_list(h, Pa, cur);
-    Pa.rzero = Pa.rzero2 = nullptr;
-    slot = time_begin(h, 2, h->rs);
-    // few, dense workgroups: this launch has a whole step to finish, what matters is that it leaves the CUs to the step kernel
-    launch_mode<MODE_PREFETCH>(h, Pa, nullptr, PREFETCH_MAX_ENVS, h->rs, h->rl_cap[cur]);
-    time_end(h, slot, h->rs);
-    HIP_TRY(h, hipEventRecord(h->ev_refill, h->rs));
-    h->refill_pending = true;
     h->parity = nxt;
   }
   h->pp ^= 1;
@@ -1701,14 +1759,18 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
   if (mode == MODE_RESET) {
     const bool pf = h->prefetch && h->cfg.auto_reset;
     if (pf) {
-      if (h->refill_pending) HIP_TRY(h, hipStreamWaitEvent(s, h->ev_refill, 0));
       if (!h->rec_seed_valid || h->rec_seed != h->seed) {  // records are keyed with the seed: a new one invalidates them all
         HIP_TRY(h, hipMemsetAsync(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)N, s));
         h->rec_seed = h->seed;
         h->rec_seed_valid = true;
         h->dirty_steps = h->cfg.max_episode_steps + 1;
+      } else if (mask != nullptr) {
+        // the slots the last step consumed are refilled by the NEXT step's launch; a partial reset must not lose them
+        KParams Pp = P;
+        use_list(h, Pp, (h->parity + 2) % 3);
+        launch_mode<MODE_PREFETCH>(h, Pp, nullptr, PREFETCH_MAX_ENVS, s, h->rl_cap[0]);
       }
-      HIP_TRY(h, hipMemsetAsync(h->d_rcount, 0, 5 * sizeof(int), s));  // (nothing is in flight here)
+      HIP_TRY(h, hipMemsetAsync(h->d_rcount, 0, 5 * sizeof(int), s));
       use_list(h, P, 3);
     }
     launch_mode<MODE_RESET>(h, P, nullptr, GROUP, s);
@@ -1811,7 +1873,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     const long n = cfg->num_envs;
     // prefetched episode records (below): the refill of ~2 % of the envs runs beside the step kernel, 32 envs per workgroup
     bool want_prefetch = cfg->env_kind != URGYM_ENV_ORI;
-    if (const char* ov = getenv("URGYM_PREFETCH")) want_prefetch = atoi(ov) != 0;
+    if (const char* ov = getenv("URGYM_PREFETCH")) want_prefetch = want_prefetch && atoi(ov) != 0;  // (Ori: inline reset, below)
     if (want_prefetch && cfg->auto_reset) {
       const long refill = n / 1600;
       slots -= refill < slots / 8 ? refill : slots / 8;
@@ -1872,13 +1934,6 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       if (pe == hipSuccess) pe = hipMalloc((void**)&h->d_rcount, sizeof(int) * 5);
       if (pe == hipSuccess) pe = hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * nn);
       if (pe == hipSuccess) pe = hipMemset(h->d_rcount, 0, sizeof(int) * 5);
-      if (pe == hipSuccess) {  // lowest priority: the refill should take the slots the step kernel leaves free, not compete for them
-        int least = 0, greatest = 0;
-        hipDeviceGetStreamPriorityRange(&least, &greatest);
-        pe = hipStreamCreateWithPriority(&h->rs, hipStreamNonBlocking, least);
-      }
-      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_step, hipEventDisableTiming);
-      if (pe == hipSuccess) pe = hipEventCreateWithFlags(&h->ev_refill, hipEventDisableTiming);
       if (pe != hipSuccess) {
         release_prefetch(h);
         if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
@@ -1926,9 +1981,8 @@ int urgym_bind(void* handle, const urgym_buffers* b) {
     return fail(h, URGYM_ERR_ARG, "urgym_bind: an obstacle buffer pointer is null");
   if (h->prefetch) {  // records belong to the state that was bound before
     hipSetDevice(h->device);
-    if (h->rs) hipStreamSynchronize(h->rs);
     HIP_TRY(h, hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)h->cfg.num_envs));
-    h->refill_pending = false;
+    HIP_TRY(h, hipMemset(h->d_rcount, 0, sizeof(int) * 5));
     h->rec_seed_valid = false;
     h->dirty_steps = h->cfg.max_episode_steps + 1;
   }
@@ -2011,6 +2065,8 @@ int urgym_enable_timing(void* handle, int enable) {
   Handle* h = (Handle*)handle;
   if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
   h->timing = enable != 0;
+  h->timing_every = enable > 1 ? enable : 1;
+  h->timing_tick = 0;
   h->ev_used = 0;
   return URGYM_OK;
 }

@@ -286,8 +286,9 @@ class UR5ReachVectorEnv:
         return out.cpu().numpy()
 
     # ------------------------------------------------------------------------------------------------ timing
-    def enable_timing(self, on=True):
-        _native.check(self.lib.urgym_enable_timing(self._h, int(on)), self._h)
+    def enable_timing(self, on=True, every=1):
+        """HIP events around the step launch; every=k times each k-th step only (a pair of events costs the stream ~6 us)."""
+        _native.check(self.lib.urgym_enable_timing(self._h, (max(1, int(every)) if on else 0)), self._h)
 
     def query_timing(self):
         """(avg step-kernel us, avg reset-kernel us, #step launches) since the last query — HIP events on the launch stream."""
