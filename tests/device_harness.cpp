@@ -25,7 +25,7 @@ static ShapeDesc desc(int type, const double* par, double* margin) {
 
 extern "C" int harness_closest(int type_a, const double* par_a, const double* pose_a, int type_b, const double* par_b,
                                const double* pose_b, double threshold, double* out) {
-  static HostTables tabs = build_host_tables();
+  const HostTables& tabs = build_host_tables();
   HullGraph g{&UR5E_HULL_VERTS[0][0], tabs.recs.data(), tabs.dirmap.data()};
   double ma, mb;
   ShapeDesc A = desc(type_a, par_a, &ma), B = desc(type_b, par_b, &mb);

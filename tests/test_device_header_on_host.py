@@ -58,3 +58,27 @@ def test_device_gjk_matches_oracle_on_host(harness, oracle, other):
         bad += d > 1e-9
     # the few that differ are queries at which Bullet's own answer jumps under 1e-14 perturbations
     assert bad <= 3 and worst < 1e-4, (bad, worst)
+
+
+def test_exactly_tied_support_values_go_to_the_scans_vertex(harness, oracle):
+    """Regression (round 2): near convergence the vertices of the closest face can tie to the last bit.  The oracle's scan keeps the
+    first maximum (lowest id); a climb that only moves to strictly better neighbours ended wherever it had started, so a finer
+    direction map changed link 3 of this Obs state by 1.5e-7 m.  The record chains now list the vertex and its neighbours by
+    descending id and the device keeps `>=`, which walks ties down to the scan's vertex."""
+    from ur_gym_amd import _abi
+
+    n = 2048
+    orc = oracle.OracleEnv(_abi.ENV_OBS, n, threads=8, auto_reset=0)
+    orc.reset(seed=47)
+    rng = np.random.default_rng(47)
+    for _ in range(11):
+        orc.step(rng.uniform(-1, 1, (n, 6)).astype(np.float32))
+    e, link = 1593, 3
+    rot, pos = oracle.fk(orc.buf["q"][:, e])
+    pa, xa = np.array([link, 0.0, 0.0]), np.r_[pos[link], Rot.from_matrix(rot[link]).as_quat()]
+    pb, xb = np.array([0.05, 0.4, 0.0]), np.r_[orc.buf["obst_pos"][:, e], orc.buf["obst_quat"][:, e]]
+    dp = C.POINTER(C.c_double)
+    out = np.zeros(2)
+    harness.harness_closest(0, pa.ctypes.data_as(dp), xa.ctypes.data_as(dp), 1, pb.ctypes.data_as(dp), xb.ctypes.data_as(dp), 5.0, out.ctypes.data_as(dp))
+    assert abs(out[0] - orc.buf["link_dist"][link - 2, e]) < 1e-13
+    orc.close()

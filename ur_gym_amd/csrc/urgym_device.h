@@ -199,12 +199,12 @@ struct ShapeDesc {
   double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
 };
 
-// Convex-hull tables in global memory (L2-resident, < 1 MB, shared by every workgroup).
-// The surface graph of each hull (Qhull triangulation, data/ur5e_model.h) is stored as NEIGHBOUR RECORDS: record i
-// (i = global vertex id) holds the ids AND the exact float64 coordinates of up to 8 neighbours of vertex i, so one hill-
-// climbing step is a single round trip of wide, independent loads (224 contiguous bytes) instead of the dependent
-// chain offset -> ids -> coordinates.  Vertices with more than 8 neighbours chain further records through `next`;
-// unused slots repeat the vertex itself (never "better", the comparison is strict).
+// Convex-hull tables in global memory (L2-resident, ~2 MB, shared by every workgroup).
+// The surface graph of each hull (Qhull triangulation, data/ur5e_model.h) is stored as RECORD CHAINS: record i (i = global
+// vertex id) holds the ids AND the exact float64 coordinates of eight entries -- vertex i itself and its neighbours, by
+// descending id -- so one hill-climbing step is a single round trip of wide, independent loads (224 contiguous bytes) instead
+// of the dependent chain offset -> ids -> coordinates.  Vertices with more than 7 neighbours chain further records through
+// `next`; unused slots of the last record repeat the lowest id (urgym_tables_host.h).
 struct alignas(16) D2 {
   double a, b;
 };
@@ -214,16 +214,20 @@ struct alignas(16) U8 {
 struct alignas(16) NbrRec {
   int next;  // next record of the same vertex, -1 = none
   int pad[3];
-  U8 id;           // neighbour ids (global vertex ids)
-  D2 x[4], y[4], z[4];  // neighbour j: (x[j/2], y[j/2], z[j/2]).{a|b}
+  U8 id;           // entry ids (global vertex ids)
+  D2 x[4], y[4], z[4];  // entry j: (x[j/2], y[j/2], z[j/2]).{a|b}
 };
 static_assert(sizeof(NbrRec) == 224, "record layout");
 // Direction map: for each hull a cube map (6 faces x DIRMAP_G x DIRMAP_G cells) of the support vertex of the cell's centre
-// direction.  The hill climb STARTS there, one or two edges away from the answer, instead of walking across the hull from a
-// seed or from the previous iteration's vertex: with those starts 6 % of the searches needed 15 or more neighbour records,
-// so practically every wave-wide iteration paid for such a walk; from the map the mean is 1.4 records and 99.3 % need at
-// most 4.  The map only picks the start — the answer is still the exact float64 arg-max the climb ends at.
-constexpr int DIRMAP_G = 32;
+// direction.  The hill climb STARTS there, usually AT the answer, instead of walking across the hull from a seed or from the
+// previous iteration's vertex: with those starts 6 % of the searches needed 15 or more records, so practically every wave-wide
+// iteration paid for such a walk.  A wave pays the maximum over its lanes: 2.3 rounds per search with 32 x 32 cells, 2.0 with
+// 128 x 128 (1.06 on average; 1.2 MB for the six hulls, L2-resident): +9 % env-steps/s.  The map only picks the start -- the
+// answer is still the exact float64 arg-max the climb ends at.
+#ifndef URGYM_DIRMAP_G
+#define URGYM_DIRMAP_G 128
+#endif
+constexpr int DIRMAP_G = URGYM_DIRMAP_G;
 constexpr int DIRMAP_CELLS = 6 * DIRMAP_G * DIRMAP_G;  // per hull
 struct HullGraph {
   const double* __restrict__ verts;           // [NV][3] exact link-frame vertices
@@ -266,9 +270,14 @@ __device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) {
 
 // branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together).  Only the
 // value and the id are tracked; the winner's coordinates are fetched once, when the climb has ended.
+// ">=": a record chain lists the vertex itself and its neighbours by DESCENDING id (urgym_tables_host.h), so among exactly tied
+// values the LOWEST id is the one kept -- the vertex the oracle's scan (first maximum) returns.  Near convergence the vertices of
+// the closest face tie to the last bit now and then; without this rule the answer would depend on where the climb started.  (The
+// maximisers of a linear function on a convex polytope form a face, whose vertices are connected: walking ties downwards in id
+// ends at the scan's vertex.)
 __device__ __forceinline__ void keep_better(double x, double y, double z, int id, D3 d, double& best, int& nxt) {
   const double t = vdot3(x, y, z, d);
-  const bool g = t > best;
+  const bool g = t >= best;
   best = g ? t : best;
   nxt = g ? id : nxt;
 }
@@ -288,16 +297,14 @@ __device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, co
 // Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
 // On a convex polytope a vertex with no better neighbour is a global maximiser of the linear function, so this is
 // the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph).  The start comes
-// from the direction map; one climbing step = one round trip: the whole 224-byte record of the current vertex at once.
+// from the direction map; one climbing step = one round trip: the whole 224-byte record of the current vertex at once
+// (the vertex itself is one of its entries, so a round ranks it together with its neighbours).
 __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d) {
   int cur = g.dirmap[h * DIRMAP_CELLS + dirmap_cell(d)];
-  const double* p0 = g.verts + 3 * cur;
-  D3 pt = d3(p0[0], p0[1], p0[2]);
-  double best = vdot3(pt.x, pt.y, pt.z, d);
-  bool moved = false;
   for (;;) {
     int nxt = cur;
     int rec = cur;
+    double best = -1.0e300;
     do {
       const NbrRec& R = g.recs[rec];
       const int nextrec = R.next;
@@ -308,13 +315,9 @@ __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d
     } while (rec >= 0);
     if (nxt == cur) break;
     cur = nxt;
-    moved = true;
   }
-  if (moved) {  // one more load for the winner's coordinates
-    const double* p = g.verts + 3 * cur;
-    pt = d3(p[0], p[1], p[2]);
-  }
-  return pt;
+  const double* p = g.verts + 3 * cur;  // one more load for the winner's coordinates
+  return d3(p[0], p[1], p[2]);
 }
 
 __device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d) {

@@ -1828,7 +1828,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   memcpy(t.joint_rot, UR5E_JOINT_ROT, sizeof(t.joint_rot));
   memcpy(t.joint_xyz, UR5E_JOINT_XYZ, sizeof(t.joint_xyz));
   memcpy(t.capsule, UR5E_CAPSULE, sizeof(t.capsule));
-  HostTables tabs = build_host_tables();
+  const HostTables& tabs = build_host_tables();
   e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
   if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpyToSymbol(c_tab)", e); }
   auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
