@@ -62,6 +62,7 @@ constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 #define URGYM_REFILL_MIN 16
 #endif
 constexpr int REFILL_MIN = URGYM_REFILL_MIN;
+constexpr int SC_FRAMES = 19, SC_FIELDS = SC_FRAMES + 72;  // rows of KParams::sc_scratch
 // bits of the per-env culling mask: table vs links 2..6, track vs links 2..6, the nine self pairs
 constexpr int PAIR_TABLE = 0, PAIR_TRACK = 5, PAIR_SELF = 10;
 __host__ __device__ constexpr int self_pair_bit(int la, int lb) {  // (1,3)(1,4)(1,5)(1,6)(2,4)(2,5)(2,6)(3,5)(3,6)
@@ -117,10 +118,12 @@ struct KParams {
   int* rcount;      // number of entries in rlist
   int rcap;         // capacity of rlist
   double* ld_scratch;  // [5][N]: the link distances of the running step (STEP keeps them here, not in LDS)
-  double* sc_scratch;  // [19][N]: STEP's per-env set-up cache, written by the env's P1 lane and read by every later draw of the
+  double* sc_scratch;  // [SC_FIELDS][N]: STEP's per-env set-up cache, written by the env's P1 lane and read by every later draw of the
                        // same workgroup: rows 2k / 2k+1 = sin / cos of joint k after the action, rows 12..18 = obstacle position +
-                       // quaternion after this step's motion.  A draw then costs the chain products only (the six float64 sincos of
-                       // a full forward-kinematics pass were three quarters of a set-up).
+                       // quaternion after this step's motion (the six float64 sincos of a full forward-kinematics pass were three
+                       // quarters of a set-up); with check_collision, rows SC_FRAMES + 12 (link - 1) .. + 11 = the frame of each
+                       // link from P1's culling pass (3 x 3 rotation, then position), so that a draw loads its operand frame
+                       // instead of multiplying the chain up again.
   int* rzero;       // a list counter this launch arms (sets to 0) for a later launch, or null
   int* rzero2;      // a second one
   int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
@@ -717,6 +720,13 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         if (use_cache) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }  // (this lane stored them above)
         else sincos(q[k], &sn, &cs);
         fk_joint(T, k, sn, cs);
+        if (use_cache) {  // the frame of link k + 1: later draws read it instead of multiplying the chain up again
+#pragma unroll
+          for (int j = 0; j < 9; j++) SOA(P.sc_scratch, SC_FRAMES + 12 * k + j, n, N) = T.r[j];
+          SOA(P.sc_scratch, SC_FRAMES + 12 * k + 9, n, N) = T.t.x;
+          SOA(P.sc_scratch, SC_FRAMES + 12 * k + 10, n, N) = T.t.y;
+          SOA(P.sc_scratch, SC_FRAMES + 12 * k + 11, n, N) = T.t.z;
+        }
         const int link = k + 1;
         const double* c = c_tab.capsule[k];
         const D3 b0 = apply(T, d3(c[0], c[1], c[2])), b1 = apply(T, d3(c[3], c[4], c[5]));
@@ -812,13 +822,24 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         if (!finite) return false;
       }
       X3 T = identity_x3(), TA = identity_x3();
+      if (cached && cfg.check_collision) {  // P1's culling pass left the link frames in the cache (same fk_joint chain, same bits)
+        auto frame = [&](int link, X3& F) {
+#pragma unroll
+          for (int j = 0; j < 9; j++) F.r[j] = SOA(P.sc_scratch, SC_FRAMES + 12 * (link - 1) + j, n, N);
+          F.t = d3(SOA(P.sc_scratch, SC_FRAMES + 12 * (link - 1) + 9, n, N), SOA(P.sc_scratch, SC_FRAMES + 12 * (link - 1) + 10, n, N),
+                   SOA(P.sc_scratch, SC_FRAMES + 12 * (link - 1) + 11, n, N));
+        };
+        frame(lb, T);
+        if (kind == Q_SELF) frame(la, TA);
+      } else {
 #pragma unroll 1
-      for (int k = 0; k < lb; k++) {
-        double sn, cs;
-        if (cached) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }
-        else sincos(LDS_Q ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
-        fk_joint(T, k, sn, cs);
-        if (k + 1 == la) TA = T;
+        for (int k = 0; k < lb; k++) {
+          double sn, cs;
+          if (cached) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }
+          else sincos(LDS_Q ? s_q[k][e] : joint_of_step<MODE>(P, actions, n, k), &sn, &cs);
+          fk_joint(T, k, sn, cs);
+          if (k + 1 == la) TA = T;
+        }
       }
       if (kind == 3) {
         X3 To;
@@ -1466,7 +1487,7 @@ struct Handle {
   int device = 0;
   int obs_dim = 0, goal_dim = 0;
   double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
-  double* d_sc_scratch = nullptr;  // [19][N] set-up cache of the running step
+  double* d_sc_scratch = nullptr;  // [SC_FIELDS][N] set-up cache of the running step
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
   unsigned short* d_dirmap = nullptr;
@@ -1838,7 +1859,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   };
   e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
   if (e == hipSuccess && !(getenv("URGYM_SETUP_CACHE") && atoi(getenv("URGYM_SETUP_CACHE")) == 0))  // =0: every draw recomputes (tuning / tests)
-    e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * 19 * (size_t)cfg->num_envs);
+    e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * SC_FIELDS * (size_t)cfg->num_envs);
   if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
