@@ -31,7 +31,7 @@ blocks = min(8192, (args.num_envs + groups - 1) // groups)
 if args.reset_kernel:
     groups = int(os.environ.get('URGYM_RESET_ENVS', '4'))
     blocks = 2048  # upper bound; only the workgroups of the LAST launch are kept below
-W, S = int(os.environ.get("URGYM_WAVES", "4")), 12
+W, S = int(os.environ.get("URGYM_WAVES", "4")), 20
 buf = np.zeros(blocks * W * S, dtype=np.uint64)
 lib = env.lib
 lib.urgym_debug_stamps.argtypes = [C.c_void_p, C.c_int]
@@ -59,6 +59,15 @@ draws = st[:, :, 5] >> 32
 loop = (st[:, :, 4] - st[:, :, 3])
 print(f"  loop trips per wave: mean {trips.mean():.1f} max {trips.max()}   draws per wave: mean {draws.mean():.1f}")
 print(f"  time per loop trip: {us(loop.sum()) / trips.sum():.2f} us")
+if not args.reset_kernel:
+    sect = st[:, :, 12:18].astype(np.float64)
+    # section i ends at mark i (urgym_device.h URGYM_TRIP_MARK / the kernel's SECTION): 0 is never marked
+    names = ("(unused)", "support of A (pose transform, hull climb)", "support of B, exits, simplex vertex stored",
+             "simplex: closest point, reduction, convergence tests", "result handling", "polling, draw, set-up")
+    tot = sect.sum()
+    print("  wave time inside the loop by section (microseconds per trip; share):")
+    for i, nm in enumerate(names):
+        print(f"    {nm:48s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
 blk = st[:, :, 7].max(axis=1) - st[:, :, 0].min(axis=1)
 print(f"  block lifetime: mean {us(blk.mean()):.1f} us, max {us(blk.max()):.1f} us; kernel span {us(st[:, :, 7].max() - st[:, :, 0].min()):.1f} us")
 

@@ -20,6 +20,20 @@ using std::fma; using std::sqrt; using std::fabs; using std::fmin; using std::fm
 #define URGYM_LDS __attribute__((address_space(3)))
 #endif
 
+// diagnostic hook (-DURGYM_STAMPS build of urgym_hip.hip, tools/phase_stamps.py): cycles per section of a GJK iteration, summed
+// in a per-wave LDS clock (clk[0] = last mark, clk[1 + i] = cycles of section i).  Nothing of it is compiled into the product.
+#if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+#define URGYM_TRIP_MARK(i) trip_mark(r.clk, i)
+__device__ __forceinline__ void trip_mark(URGYM_LDS unsigned long long* clk, int i) {
+  if (clk == nullptr) return;  // a search outside the instrumented loop
+  const unsigned long long t = __builtin_amdgcn_s_memtime();
+  clk[1 + i] += t - clk[0];
+  clk[0] = t;
+}
+#else
+#define URGYM_TRIP_MARK(i) do {} while (0)
+#endif
+
 namespace urgym {
 
 struct D3 {
@@ -393,6 +407,9 @@ struct GjkRun {
   int info;         // GJK_* flags, valid when done
   double core;      // result (core distance), valid when done
   bool done;
+#if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+  URGYM_LDS unsigned long long* clk;  // diagnostic build: the wave's section clock
+#endif
 };
 __device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0) {
   r.v = v0;
@@ -402,6 +419,9 @@ __device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0) {
   r.info = 0;
   r.core = 0.0;
   r.done = false;
+#if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+  r.clk = nullptr;
+#endif
 }
 // exit of the search: what Bullet does after its loop (checkSimplex / degenerate cases)
 __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int degenerate) {
@@ -424,6 +444,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   D3 w;
   {
     D3 p = apply(T, support_local(g, A, rotT(T, -r.v)));
+    URGYM_TRIP_MARK(1);
     D3 q = support_local(g, B, r.v);
     w = p - q;
   }
@@ -438,6 +459,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   if (f0 <= f1) { gjk_finish(r, true, (f0 <= 0.0) ? 2 : 11); return; }
   stw(T, r.n, w);
   int n = r.n + 1;
+  URGYM_TRIP_MARK(2);
   // ---- closest point of the simplex to the origin + vertex reduction
   D3 nv = d3(0, 0, 0);
   bool valid = true;
@@ -517,6 +539,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
       reduce = false;
     }
   }
+  URGYM_TRIP_MARK(3);
   if (reduce) {
     // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
     if (n >= 4 && !ud) { n--; }

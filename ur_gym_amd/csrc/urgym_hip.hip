@@ -504,7 +504,7 @@ __device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double
 #ifndef URGYM_STAMP_MODE
 #define URGYM_STAMP_MODE 0  /* MODE_STEP; 1 = the auto-reset kernel */
 #endif
-constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 12;
+constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 20;  // 0..11 phases (tools/phase_stamps.py), 12..19 cycles per section of the loop
 __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP(k, v)                                                                                         \
   do {                                                                                                      \
@@ -544,6 +544,9 @@ struct EnvLds {
   int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
   // ... and per-lane slots
   double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
+#ifdef URGYM_STAMPS
+  unsigned long long s_clk[WAVES][8];        // diagnostic build: per-wave section clock of the loop
+#endif
 };
 
 // WITH_EPA: compiled with the penetration-depth phase (the host picks the instance: a STEP launch of Dyn / Sta with the
@@ -916,10 +919,23 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     }
     STAMP_TIME(3);
     int trips = 0, draws = 0;
+#ifdef URGYM_STAMPS
+    // cycles of this wave per section of a loop trip (a section ends at its mark): 1 support of A, 2 support of B + exits, 3 simplex +
+    // reduction + convergence tests, 4 result handling, 5 polling + draw + set-up (a mark that no lane of a trip reaches adds its
+    // time to the next section)
+    URGYM_LDS unsigned long long* clk = (URGYM_LDS unsigned long long*)&L.s_clk[wv][0];
+    if (lane < 8) clk[lane] = 0;
+    if (busy) run.clk = clk;
+    clk[0] = __builtin_amdgcn_s_memtime();
+#define SECTION(i) trip_mark(clk, i)
+#else
+#define SECTION(i) do {} while (0)
+#endif
     for (;;) {
       trips++;
       if (busy) {
         gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
+        SECTION(3);
         if (run.done) {
           const double msum = margin_sum();
           if (kind == 3 || exact) {
@@ -940,6 +956,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
           busy = false;
         }
       }
+      SECTION(4);
       // (atomic loads: other waves change both words while this one polls them; a plain read could legally be hoisted)
       const bool more_tickets = __hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_tickets;
       const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
@@ -960,11 +977,18 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         if (item != NO_ITEM) {
           busy = setup(item);
           if (busy) gjk_begin(run, v0);
+#ifdef URGYM_STAMPS
+          if (busy) run.clk = clk;
+#endif
         }
       }
+      SECTION(5);
       // nothing left for this wave to draw (STEP: and the pair masks have been published)
       if (__ballot(busy) == 0ull && !more_tickets && !more_pairs && p1_published) break;
     }
+#ifdef URGYM_STAMPS
+    for (int i = 0; i < 6; i++) STAMP(12 + i, clk[1 + i]);
+#endif
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
     // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  A wave that has left
@@ -1905,6 +1929,18 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     if (envs < GROUP) envs = (envs + 7) / 8 * 8;
     if (envs > STEP_MAX_ENVS) envs = STEP_MAX_ENVS;
     h->step_envs = (int)envs;
+    // One round, three workgroups per CU: the first 2 x CUs workgroups (two per CU, dispatched first) serve E1 envs each, the third
+    // one of a CU 0.7 E1.  A CU with three resident workgroups advances each of them more slowly than one with two, and the third
+    // starts last; giving it less work evens the finishing times out (N = 65536: 512 x 100 + 205 x 70 instead of 721 x 91, +5 %,
+    // profiles/r2/exp_two_tier_one_round.jsonl).  URGYM_STEP_TIERS=0 keeps the uniform geometry.
+    if (rounds == 1 && per_cu == 3 && slots > 2L * cus) {
+      const long big = 2L * cus, rest = slots - big;
+      const long e1 = (10 * n + (10 * big + 7 * rest) - 1) / (10 * big + 7 * rest);
+      if (e1 >= 64 && e1 <= STEP_MAX_ENVS && n > big * e1) {  // (below ~40 000 envs the uniform geometry is as fast or faster)
+        const long e2 = (n - big * e1 + rest - 1) / rest;
+        h->step_envs = (int)e1; h->big_blocks = (int)big; h->tail_envs = (int)(e2 < 1 ? 1 : e2);
+      }
+    }
     // auto-reset kernel: ~1 % of the envs finish per step; keep that to about one workgroup per CU (4 envs at N = 65536,
     // 8 at 262144): it is pure latency, smaller workgroups shorten the wave-wide maxima, more than one per CU queue up
     int renvs = 4;
@@ -1912,12 +1948,14 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     h->reset_envs = renvs;
     if (const char* ov = getenv("URGYM_STEP_ENVS")) {
       const int v = atoi(ov);
-      if (v >= 1 && v <= STEP_MAX_ENVS) h->step_envs = v;
+      if (v >= 1 && v <= STEP_MAX_ENVS) { h->step_envs = v; h->big_blocks = 0; h->tail_envs = 0; }
     }
     if (const char* ov = getenv("URGYM_STEP_TIERS")) {  // "E1,B,E2": B workgroups of E1 envs, then workgroups of E2 (tuning / tests)
       int e1 = 0, b = 0, e2 = 0;
       if (sscanf(ov, "%d,%d,%d", &e1, &b, &e2) == 3 && e1 >= 1 && e1 <= STEP_MAX_ENVS && e2 >= 1 && e2 <= STEP_MAX_ENVS && b >= 1) {
         h->step_envs = e1; h->big_blocks = b; h->tail_envs = e2;
+      } else if (atoi(ov) == 0) {  // "0": uniform workgroups
+        h->step_envs = (int)envs; h->big_blocks = 0; h->tail_envs = 0;
       }
     }
     if (const char* ov = getenv("URGYM_RESET_ENVS")) {
@@ -1967,8 +2005,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       }
     }
     if (getenv("URGYM_VERBOSE"))
-      fprintf(stderr, "[urgym] device %d: %d CUs x %d resident step workgroups; N = %ld -> %d envs per step workgroup (%ld workgroups), %d per reset workgroup\n",
-              device, cus, per_cu, n, h->step_envs, (n + h->step_envs - 1) / h->step_envs, h->reset_envs);
+      fprintf(stderr, "[urgym] device %d: %d CUs x %d resident step workgroups; N = %ld -> %d envs per step workgroup (%d of them, then %d envs each), %d per reset workgroup\n",
+              device, cus, per_cu, n, h->step_envs, h->big_blocks > 0 ? h->big_blocks : (int)((n + h->step_envs - 1) / h->step_envs), h->tail_envs, h->reset_envs);
     if (getenv("URGYM_VERBOSE")) fprintf(stderr, "[urgym] prefetched episode records: %s\n", h->prefetch ? "on" : "off");
   }
   *handle = h;
