@@ -819,6 +819,39 @@ def test_ori_auto_reset_paths_match_oracle(oracle, monkeypatch, prefetch):
     env.close()
 
 
+@pytest.mark.parametrize("level", ["0", "2"])
+def test_setup_cache_levels_match_oracle(oracle, monkeypatch, level):
+    """URGYM_SETUP_CACHE: 0 = every draw of a query recomputes its operands, 2 = the link frames of the culling pass are cached too
+    (default 1: sin / cos of the joints + the advanced obstacle pose).  All levels must give the default's results: same oracle, and
+    bitwise the same state as a default-level env stepped beside it.
+    (Seed 61 is also the regression case of the culling bound: in step 12 env 591's wrist is 0.00988 m from the table, inside the
+    0.01 m contact margin by less than the hull's own collision margin; the capsule bound of round 1 / early round 2 left that
+    margin out and culled the pair, so the HIP path missed the collision the oracle and Bullet report.)"""
+    kind, n, steps = _abi.ENV_DYN, 1500, 12
+    ref_env = make_vec("UR5DynReach-v1", num_envs=n, seed=61)
+    monkeypatch.setenv("URGYM_SETUP_CACHE", level)
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=61)
+    orc = oracle.OracleEnv(kind, n, threads=8)
+    for e in (ref_env, env):
+        e.reset(seed=61)
+    orc.reset(seed=61)
+    rng = np.random.default_rng(61)
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        ref_env.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        want = ref_env.get_state()
+        step_both(oracle, kind, env, orc, a, where=f"setup cache {level} step {t}")
+        ref_env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())  # (step_both resynchronised `env` the same way)
+        got = env.get_state()
+        for k in ("q", "obst_pos", "obst_quat", "step_count", "episode_id"):
+            assert np.array_equal(want[k], got[k]), (k, t)
+        assert np.array_equal(np_(ref_env.buf["observation"]), np_(env.buf["observation"])), t
+        assert np.array_equal(np_(ref_env.buf["reward"]), np_(env.buf["reward"])), t
+    env.close()
+    ref_env.close()
+
+
 def test_refresh_with_a_penetrating_obstacle_reports_the_depth(oracle):
     """set_goal_and_obstacle (reach.py:328-335) with the obstacle put INTO the arm: link_dist of the touched links is the negative
     penetration depth (EPA in the REFRESH kernel), collision is flagged, and the next step goes on from there like the oracle's."""

@@ -20,4 +20,6 @@ make -C ur_gym_amd/csrc stamps > /dev/null 2>&1
 timeout -k 10 120 python tools/phase_stamps.py --env UR5ObsReach-v1 --num-envs 16384 --envs-per-block 32 > $OUT/stamps_obs_n16384_e32.txt 2>&1
 grep -E "first set-up|GJK loop|barrier wait|P4  |loop trips|per loop trip|block lifetime|concurrent|timeline" $OUT/stamps_obs_n16384_e32.txt
 timeout -k 10 120 python tools/phase_stamps.py --num-envs 65536 --envs-per-block 91 > $OUT/stamps_dyn_n65536_e91.txt 2>&1
-grep -E "first set-up|GJK loop|barrier wait|P4  |loop trips|per loop trip|block lifetime|concurrent|timeline" $OUT/stamps_dyn_n65536_e91.txt
+timeout -k 10 120 python tools/phase_stamps.py --num-envs 65536 --tiers 100,512,70 > $OUT/stamps_dyn_n65536_tiers.txt 2>&1
+timeout -k 10 120 python tools/phase_stamps.py --num-envs 728 --envs-per-block 91 > $OUT/stamps_dyn_n728_e91.txt 2>&1
+grep -E "first set-up|GJK loop|barrier wait|P4  |loop trips|per loop trip|block lifetime|concurrent|timeline|%" $OUT/stamps_dyn_n65536_tiers.txt

@@ -15,8 +15,11 @@ ap.add_argument("--steps", type=int, default=12)
 ap.add_argument("--reset-kernel", action="store_true", help="library built with -DURGYM_STAMP_MODE=1: stamps of the auto-reset kernel")
 ap.add_argument("--lib", default="liburgym_stamps.so")
 ap.add_argument("--envs-per-block", type=int, default=64, help="forces URGYM_STEP_ENVS so that the stamp layout is known")
+ap.add_argument("--tiers", default="", help="E1,B,E2: two-tier geometry (URGYM_STEP_TIERS) instead of --envs-per-block")
 args = ap.parse_args()
 os.environ["URGYM_STEP_ENVS"] = str(args.envs_per_block)
+if args.tiers:
+    os.environ["URGYM_STEP_TIERS"] = args.tiers
 _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", args.lib)
 from ur_gym_amd import make_vec
 
@@ -28,6 +31,10 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 groups = args.envs_per_block
 blocks = min(8192, (args.num_envs + groups - 1) // groups)
+if args.tiers:
+    e1, nb, e2 = (int(x) for x in args.tiers.split(","))
+    groups = f"{nb} x {e1}, then {e2}"
+    blocks = min(8192, nb + (args.num_envs - nb * e1 + e2 - 1) // e2)
 if args.reset_kernel:
     groups = int(os.environ.get('URGYM_RESET_ENVS', '4'))
     blocks = 2048  # upper bound; only the workgroups of the LAST launch are kept below

@@ -128,6 +128,7 @@ struct KParams {
   int* rzero2;      // a second one
   int fallback_on;  // STEP with prefetch: 1 = the RESET / PREFETCH fallback launches follow this step (records may be stale)
   int prefetch;     // 1: STEP resets finished envs inline from valid records; RESET files refill entries
+  int sc_frames;    // 1: sc_scratch also carries the link frames (rows SC_FRAMES ..)
   int inline_ori;   // 1: STEP of UR5OriReach-v1 resets finished envs inline (its reset is one goal draw, reach.py:197-200): no RESET launch
   float neutral_ach[6];  // end-effector position + Euler angles of the neutral pose, float32 as _get_obs casts them (set at create)
 };
@@ -714,7 +715,10 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     // culling: one FK pass over the six links, world bounding capsules, segment-box / segment-segment lower bounds
     uint32_t pairs = 0;
     if (live && cfg.check_collision && MODE != MODE_RESET && MODE != MODE_PREFETCH) {
-      const double lim = cfg.collision_margin + 1e-6;
+      // The capsules bound the hull VERTICES; Bullet's hull is those vertices inflated by its margin (the boxes are shrunk cores plus
+      // their margin, i.e. inside the full boxes used here), so a pair can be closer than its capsules by one hull margin (two for
+      // a self pair).  Round 2 found the bound without that term: a table contact at 0.00988 m was culled (margin 0.01).
+      const double lim = cfg.collision_margin + M_HULL + 1e-6;
       X3 T = identity_x3();
       D3 a0[3], a1[3];
 #pragma unroll
@@ -723,7 +727,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         if (use_cache) { sn = SOA(P.sc_scratch, 2 * k, n, N); cs = SOA(P.sc_scratch, 2 * k + 1, n, N); }  // (this lane stored them above)
         else sincos(q[k], &sn, &cs);
         fk_joint(T, k, sn, cs);
-        if (use_cache) {  // the frame of link k + 1: later draws read it instead of multiplying the chain up again
+        if (use_cache && P.sc_frames) {  // the frame of link k + 1: later draws read it instead of multiplying the chain up again
 #pragma unroll
           for (int j = 0; j < 9; j++) SOA(P.sc_scratch, SC_FRAMES + 12 * k + j, n, N) = T.r[j];
           SOA(P.sc_scratch, SC_FRAMES + 12 * k + 9, n, N) = T.t.x;
@@ -743,7 +747,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
 #pragma unroll
         for (int A = 1; A <= 3; A++) {
           if (A <= link - 2) {
-            if (segseg_dist(a0[A - 1], a1[A - 1], b0, b1) - c_tab.capsule[A - 1][6] - rb <= lim) pairs |= 1u << self_pair_bit(A, link);
+            if (segseg_dist(a0[A - 1], a1[A - 1], b0, b1) - c_tab.capsule[A - 1][6] - rb <= lim + M_HULL) pairs |= 1u << self_pair_bit(A, link);
           }
         }
       }
@@ -825,7 +829,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         if (!finite) return false;
       }
       X3 T = identity_x3(), TA = identity_x3();
-      if (cached && cfg.check_collision) {  // P1's culling pass left the link frames in the cache (same fk_joint chain, same bits)
+      if (cached && P.sc_frames && cfg.check_collision) {  // P1's culling pass left the link frames in the cache (same fk_joint chain, same bits)
         auto frame = [&](int link, X3& F) {
 #pragma unroll
           for (int j = 0; j < 9; j++) F.r[j] = SOA(P.sc_scratch, SC_FRAMES + 12 * (link - 1) + j, n, N);
@@ -1512,6 +1516,7 @@ struct Handle {
   int obs_dim = 0, goal_dim = 0;
   double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
   double* d_sc_scratch = nullptr;  // [SC_FIELDS][N] set-up cache of the running step
+  bool sc_frames = false;          // ... with the link frames (URGYM_SETUP_CACHE=2; default 1: without them; 0: no cache at all)
   double* d_verts64 = nullptr;
   NbrRec* d_recs = nullptr;
   unsigned short* d_dirmap = nullptr;
@@ -1633,6 +1638,7 @@ KParams make_params(Handle* h, int copy_final) {
   P.rcap = 0;
   P.ld_scratch = h->d_ld_scratch;
   P.sc_scratch = h->d_sc_scratch;
+  P.sc_frames = h->sc_frames ? 1 : 0;
   P.rzero = nullptr;
   P.rzero2 = nullptr;
   P.fallback_on = 1;
@@ -1882,8 +1888,13 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   e = hipMalloc((void**)&h->d_ld_scratch, sizeof(double) * 5 * (size_t)cfg->num_envs);
-  if (e == hipSuccess && !(getenv("URGYM_SETUP_CACHE") && atoi(getenv("URGYM_SETUP_CACHE")) == 0))  // =0: every draw recomputes (tuning / tests)
-    e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * SC_FIELDS * (size_t)cfg->num_envs);
+  // URGYM_SETUP_CACHE (tuning / tests): 0 = every draw recomputes its operands, 1 (default) = sin / cos of the joints + obstacle pose
+  // cached, 2 = the link frames too.  Measured at N = 65536 Dyn (profiles/r2/exp_setup_cache_levels.txt): 186.3 / 195.4 / 197.7 M
+  // env-steps/s at 108 / 140 / 201 MB of L2 <-> fabric traffic per launch: the frames buy 1 % for 61 MB, so they stay opt-in.
+  const int sc_level = getenv("URGYM_SETUP_CACHE") ? atoi(getenv("URGYM_SETUP_CACHE")) : 1;
+  h->sc_frames = sc_level >= 2;
+  if (e == hipSuccess && sc_level != 0)
+    e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * (h->sc_frames ? SC_FIELDS : SC_FRAMES) * (size_t)cfg->num_envs);
   if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
   if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
   if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
