@@ -852,6 +852,71 @@ def test_setup_cache_levels_match_oracle(oracle, monkeypatch, level):
     ref_env.close()
 
 
+def _pairs_near_the_margin(oracle, q, obst_pose, margin=0.01, band=2e-5):
+    """All check_collision pairs (pyb_setup.py:382-429) of one pose whose oracle distance lies within `band` of the contact margin."""
+    from scipy.spatial.transform import Rotation as Rot
+
+    rot, pos = oracle.fk(q)
+    pose = lambda l: np.r_[pos[l], Rot.from_matrix(rot[l]).as_quat()]
+    ident = [0.0, 0.0, 0.0, 1.0]
+    boxes = ((oracle.BOX, [0.55, 0.9, 0.46], np.r_[0.5, 0.0, -0.58, ident]), (oracle.BOX, [0.1, 0.55, 0.06], np.r_[0.0, 0.0, -0.06, ident]))
+    near = []
+    for l in range(2, 7):
+        others = [(oracle.CYLZ, [0.05, 0.4], obst_pose)] + list(boxes)
+        for tb, pb, xb in others:
+            d = oracle.closest(oracle.HULL, [l], pose(l), tb, pb, xb)["distance"]
+            if abs(d - margin) < band:
+                near.append((l, tb, d))
+    for la, lb in ((1, 3), (1, 4), (1, 5), (1, 6), (2, 4), (2, 5), (2, 6), (3, 5), (3, 6)):
+        d = oracle.closest(oracle.HULL, [la], pose(la), oracle.HULL, [lb], pose(lb))["distance"]
+        if abs(d - margin) < band:
+            near.append((la, lb, d))
+    return near
+
+
+def test_collision_verdict_census(oracle):
+    """check_collision over 260 000 random poses (uniform joints, obstacle anywhere around the arm) -- far more, and far more varied,
+    than the rollouts of the other tests visit: the HIP path's verdict (capsule culling, then the device GJK) against the oracle's
+    (no culling).  A verdict may differ only where a pair's distance sits within 2e-5 m of the 0.01 m contact margin."""
+    n, rounds = 65536, 4
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=3, auto_reset=False)
+    orc = oracle.OracleEnv(_abi.ENV_DYN, n, threads=8, auto_reset=0)
+    env.reset(seed=3)
+    orc.reset(seed=3)
+    rng = np.random.default_rng(2024)
+    zero = np.zeros((n, 6), np.float32)
+    differing, collisions = 0, 0
+    for r in range(rounds):
+        rpy = rng.uniform(-np.pi, np.pi, (n, 3))
+        rpy[:, 1] *= 0.5
+        quat = np.array([oracle.quat_from_euler(x) for x in rpy[:4096]])
+        quat = np.tile(quat, (n // 4096, 1))  # 4096 distinct orientations are plenty; the positions and joints are all distinct
+        pos = np.c_[rng.uniform(-0.3, 0.9, n), rng.uniform(-0.7, 0.7, n), rng.uniform(-0.05, 0.9, n)]
+        st = {"q": rng.uniform(-np.pi, np.pi, (6, n)), "obst_pos": pos.T.copy(), "obst_quat": quat.T.copy(), "obst_vel": np.zeros((9, n)),
+              "link_dist": np.zeros((5, n)), "step_count": np.full(n, 30, np.int32), "episode_id": np.ones(n, np.int32)}
+        st["q"][1] = rng.uniform(-np.pi, 0.0, n)  # shoulder mostly above the table, so that not every pose collides with it
+        env.set_state(st)
+        orc.load_state(st)
+        env.step(torch.from_numpy(zero).cuda())
+        orc.step(zero)
+        torch.cuda.synchronize()
+        got, want = np_(env.buf["collision"]).astype(bool), orc.buf["collision"].astype(bool)
+        collisions += int(want.sum())
+        for i in np.nonzero(got != want)[0]:
+            differing += 1
+            near = _pairs_near_the_margin(oracle, st["q"][:, i], np.r_[pos[i], quat[i]])
+            assert near, f"round {r} env {i}: HIP collision={got[i]} oracle={want[i]} with no pair near the margin"
+        # link distances of the poses both sides call collision-free (a colliding env ends here: what its distances hold is covered
+        # by the terminal-step tests)
+        ld = env.get_state()["link_dist"]
+        ld[:, got | want] = orc.buf["link_dist"][:, got | want]
+        slack = link_dist_slack(oracle, ld, orc.buf["link_dist"], st["q"], st["obst_pos"], st["obst_quat"])
+        assert (slack > 0).sum() <= n // 500, r
+    assert 0.05 * n * rounds < collisions < 0.95 * n * rounds  # the census exercises both verdicts
+    assert differing <= 8
+    env.close()
+
+
 def test_refresh_with_a_penetrating_obstacle_reports_the_depth(oracle):
     """set_goal_and_obstacle (reach.py:328-335) with the obstacle put INTO the arm: link_dist of the touched links is the negative
     penetration depth (EPA in the REFRESH kernel), collision is flagged, and the next step goes on from there like the oracle's."""
