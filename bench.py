@@ -283,7 +283,6 @@ def main():
                          "algorithmic_bytes_per_launch": algo,
                          "kernel": "env_step_fused<Dyn> (STEP workgroups + the refill of the previous step's episode records)" if args.env == "UR5DynReach-v1" else "step launch",
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
-                         "overlapped_refill_kernel_us": getattr(env, "last_refill_us", 0.0),
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
                          "note": "bound by the dependent float64 chain of the GJK iterations (resident waves, then VALU issue), not by HBM (DESIGN.md section 4)"},
             "anomalous_envs": anomalies,

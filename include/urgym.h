@@ -167,7 +167,9 @@ int urgym_obs_dims(int env_kind, int* obs_dim, int* goal_dim);
  * URGYM_STEP_TIERS="E1,B,E2" (B workgroups of E1 envs, then workgroups of E2), URGYM_RESET_ENVS (envs per workgroup of the
  * auto-reset kernel, 1..64), URGYM_PREFETCH (0: reset finished envs with a kernel after each step instead of inline from
  * prefetched episode records), URGYM_SETUP_CACHE (0: every draw of a query recomputes the joint sines / cosines instead of
- * reading them from the per-env cache), URGYM_VERBOSE (print the chosen geometry to stderr). */
+ * reading them from the per-env cache; 1 = default; 2: the cache also carries the link frames, +576 B per env),
+ * URGYM_STEP_TIERS=0 (uniform workgroups where the default would be two-tier), URGYM_VERBOSE (print the chosen geometry to
+ * stderr). */
 int urgym_create(const urgym_config* cfg, int device, void** handle);
 int urgym_destroy(void* handle);
 
@@ -214,9 +216,9 @@ int urgym_probe_pose_distance(void* handle, int count, const double* a6, const d
 int urgym_enable_timing(void* handle, int enable);
 int urgym_query_timing(void* handle, double* step_kernel_us, double* reset_kernel_us, int* launches);
 
-/* Average duration (us) of the overlapped refill launches covered by the most recent urgym_query_timing() call: the search
- * for the next episodes of the envs that finished, which runs on a side stream under the following step (0 when the
- * prefetched-record path is off).  Measurement hook only. */
+/* Kept for ABI v2 callers: always reports 0.  The search for the next episodes of the envs that finished used to run as a launch
+ * of its own on a side stream; it now rides in the step launch (its workgroups follow the step workgroups in one grid), so
+ * urgym_query_timing()'s step figure includes it. */
 int urgym_query_refill_timing(void* handle, double* refill_us);
 
 const char* urgym_last_error(void* handle);

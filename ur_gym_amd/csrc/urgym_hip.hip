@@ -23,7 +23,7 @@
 //
 // RESET consumes the device-side done list (no host round trip): Philox-keyed rejection sampling of reach.py:313-326 /
 // 664-683 by the whole first wave, then the neutral-pose link distances.  PREFETCH is RESET with an episode record as its
-// output; it runs on a side stream under the next step kernel.  REFRESH = Reach*.set_goal[_and_obstacle].
+// output; its workgroups ride in the NEXT step's launch (env_step_fused).  REFRESH = Reach*.set_goal[_and_obstacle].
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
