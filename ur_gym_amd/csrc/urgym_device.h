@@ -498,17 +498,20 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     int todo = 1;  // triangle: just face 0 = (w0, w1, w2)
     bool degen = false;
     if (tetra) {
+      // the four vertices once, the four plane tests as straight-line code: four independent chains the scheduler can interleave,
+      // instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
       todo = 0;
-#pragma unroll 1
-      for (int f = 0; f < 4; f++) {
-        int ia, ib, ic, io;
-        face_vertices(f, ia, ib, ic, io);
-        const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
+      const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
+      auto plane = [&](D3 a, D3 b, D3 c, D3 o, int bit) {
         const D3 nrm = cross(b - a, c - a);
-        const double signp = -dot(a, nrm), signd = dot(ldw(T, io) - a, nrm);
+        const double signp = -dot(a, nrm), signd = dot(o - a, nrm);
         if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
-        else if (signp * signd < 0.0) todo |= 1 << f;
-      }
+        else if (signp * signd < 0.0) todo |= bit;
+      };
+      plane(W0, W1, W2, w, 1);   // ABC | D
+      plane(W0, W2, w, W1, 2);   // ACD | B
+      plane(W0, w, W1, W2, 4);   // ADB | C
+      plane(W1, w, W2, W0, 8);   // BDC | A
     }
     double best = 1.0e300;
     bool any_out = false;
