@@ -450,9 +450,11 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   }
   const double delta = dot(r.v, w);
   if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { gjk_finish(r, true, 10); return; }
+  // the (up to three) vertices already in the simplex: read once, together -- the duplicate test below, the segment case and the
+  // plane tests of the tetrahedron all use them (a slot at or beyond r.n holds stale data and is masked where it matters)
+  const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
   {
-    bool in = false;
-    for (int i = 0; i < r.n; i++) in = in || (len2(ldw(T, i) - w) <= 1e-12);
+    const bool in = ((r.n > 0) & (len2(W0 - w) <= 1e-12)) | ((r.n > 1) & (len2(W1 - w) <= 1e-12)) | ((r.n > 2) & (len2(W2 - w) <= 1e-12));
     if (in) { gjk_finish(r, true, 1); return; }
   }
   const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;
@@ -469,7 +471,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     nv = w;
     reduce = false;
   } else if (n == 2) {
-    D3 s0 = ldw(T, 0);
+    D3 s0 = W0;
     D3 e = w - s0;
     double t = -dot(e, s0);
     if (t > 0.0) {
@@ -498,10 +500,9 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     int todo = 1;  // triangle: just face 0 = (w0, w1, w2)
     bool degen = false;
     if (tetra) {
-      // the four vertices once, the four plane tests as straight-line code: four independent chains the scheduler can interleave,
-      // instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
+      // the four plane tests as straight-line code on the vertices read above: four independent chains the scheduler can
+      // interleave, instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
       todo = 0;
-      const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
       auto plane = [&](D3 a, D3 b, D3 c, D3 o, int bit) {
         const D3 nrm = cross(b - a, c - a);
         const double signp = -dot(a, nrm), signd = dot(o - a, nrm);
