@@ -1359,10 +1359,11 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
   if (MODE == MODE_STEP) {
     const int base = first;
     const int cnt = min(E, N - base);
-    for (int i = tid; i < cnt * OD; i += THREADS) B.observation[(size_t)base * OD + i] = s_out[(i / OD) * 47 + (i % OD)];
+    // (streaming stores: nothing in this launch reads the rows again, and they should not push the hull tables out of L2)
+    for (int i = tid; i < cnt * OD; i += THREADS) __builtin_nontemporal_store(s_out[(i / OD) * 47 + (i % OD)], &B.observation[(size_t)base * OD + i]);
     for (int i = tid; i < cnt * GD; i += THREADS) {
-      B.achieved_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + (i % GD)];
-      B.desired_goal[(size_t)base * GD + i] = s_out[(i / GD) * 47 + OD + GD + (i % GD)];
+      __builtin_nontemporal_store(s_out[(i / GD) * 47 + OD + (i % GD)], &B.achieved_goal[(size_t)base * GD + i]);
+      __builtin_nontemporal_store(s_out[(i / GD) * 47 + OD + GD + (i % GD)], &B.desired_goal[(size_t)base * GD + i]);
     }
     if (bidx == 0 && tid == 0) B.done_count[P.pp ^ 1] = 0;  // arm the other counter
   } else if (MODE != MODE_PREFETCH) {
