@@ -73,6 +73,9 @@ if not args.reset_kernel:
              "simplex: closest point, reduction, convergence tests", "result handling", "polling, draw, set-up")
     tot = sect.sum()
     print("  wave time inside the loop by section (microseconds per trip; share):")
+    boxq, selfq, trips_self = (st[:, :, 18] & 0xFFFFFFFF), (st[:, :, 18] >> 32), st[:, :, 19]
+    print(f"  pair queries per workgroup: {boxq.sum(axis=1).mean():.1f} link <-> table / track, {selfq.sum(axis=1).mean():.1f} link <-> link; "
+          f"trips that carried a link <-> link query: {100.0 * trips_self.sum() / trips.sum():.1f} %")
     for i, nm in enumerate(names):
         print(f"    {nm:48s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
 blk = st[:, :, 7].max(axis=1) - st[:, :, 0].min(axis=1)

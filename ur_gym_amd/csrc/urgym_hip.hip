@@ -935,8 +935,14 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
 #else
 #define SECTION(i) do {} while (0)
 #endif
+#ifdef URGYM_STAMPS
+    unsigned long long n_boxq = 0, n_selfq = 0, trips_self = 0;  // census of the pair queries this wave ran / trips that carried a hull <-> hull query
+#endif
     for (;;) {
       trips++;
+#ifdef URGYM_STAMPS
+      trips_self += (__ballot(busy && kind == Q_SELF) != 0ull) ? 1 : 0;
+#endif
       if (busy) {
         gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
         SECTION(3);
@@ -970,7 +976,6 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
       const int idle_lanes = __popcll(__ballot(!busy));
       if (!busy && (idle_lanes >= REFILL_MIN || idle_lanes == 64)) {
-        draws++;
         uint32_t item = NO_ITEM;
         if (more_tickets) {
           const int t = atomicAdd(&s_ticket, 1);
@@ -979,10 +984,13 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
           if (atomicSub(&s_pending, 1) > 0) item = claim_pair();
         }
         if (item != NO_ITEM) {
+          draws++;  // (diagnostic: the draws of the lane that reports the stamps)
           busy = setup(item);
           if (busy) gjk_begin(run, v0);
 #ifdef URGYM_STAMPS
           if (busy) run.clk = clk;
+          n_boxq += __popcll(__ballot(busy && (kind == Q_TABLE || kind == Q_TRACK)));
+          n_selfq += __popcll(__ballot(busy && kind == Q_SELF));
 #endif
         }
       }
@@ -992,6 +1000,8 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     }
 #ifdef URGYM_STAMPS
     for (int i = 0; i < 6; i++) STAMP(12 + i, clk[1 + i]);
+    STAMP(18, n_boxq | (n_selfq << 32));
+    STAMP(19, trips_self);
 #endif
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
