@@ -727,8 +727,15 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
       const int e = valid ? (int)*ws.rim(c) : 0;
       const int rev = ((e & 255) << 8) | (e >> 8);
       bool found = false;
+      if (nc <= 64) {
+        // (the usual case: every candidate sits in a lane -- ask the lanes instead of reading the list back from LDS one dependent
+        //  round trip at a time, which was half of an expansion's time)
+#pragma unroll 4
+        for (int x = 0; x < nc; x++) found = found || (__builtin_amdgcn_readlane(e, x) == rev);
+      } else {
 #pragma unroll 1
-      for (int x = 0; x < nc; x++) found = found || ((int)*ws.rim(x) == rev);
+        for (int x = 0; x < nc; x++) found = found || ((int)*ws.rim(x) == rev);
+      }
       const bool hor = valid && !found;
       const unsigned long long m = __ballot(hor);
       if (hor) {
