@@ -202,7 +202,10 @@ def main():
     env.reset(seed=args.seed + 1000 * rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed + rank)
-    n_act = min(args.steps + args.warmup, 64)  # distinct action batches, cycled (random policy as demo.py:11)
+    # distinct action batches, cycled (random policy as demo.py:11).  64 is within 1 % of never repeating a batch (measured: 206.2 M
+    # env-steps/s with 64, 208.8 M with 256 or 1000, N = 65536); a SHORT cycle is a different workload -- with 16 the joints drift,
+    # the arms run into contact and 50 % more episodes end per step (170 M).  URGYM_BENCH_NACT overrides (diagnostic).
+    n_act = min(args.steps + args.warmup, int(os.environ.get("URGYM_BENCH_NACT", "64")))
     actions = torch.rand((n_act, n, 6), generator=gen, device=dev, dtype=torch.float32) * 2 - 1
     gathered = None
     gloo = dist is not None and dist.get_backend() == "gloo"
