@@ -730,7 +730,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
       if (nc <= 64) {
         // (the usual case: every candidate sits in a lane -- ask the lanes instead of reading the list back from LDS one dependent
         //  round trip at a time, which was half of an expansion's time)
-#pragma unroll 4
+#pragma unroll 1
         for (int x = 0; x < nc; x++) found = found || (__builtin_amdgcn_readlane(e, x) == rev);
       } else {
 #pragma unroll 1
