@@ -511,6 +511,32 @@ def test_launch_geometry_does_not_change_results(oracle, monkeypatch, step_envs,
     env.close()
 
 
+def test_default_two_tier_geometry_is_bitwise_the_uniform_one(monkeypatch):
+    """From about 42 000 envs up to one round of workgroups urgym_create picks a two-tier grid (the third workgroup of a CU gets
+    0.7 x the envs of the first two); URGYM_STEP_TIERS=0 keeps uniform workgroups.  Scheduling only: every output and state array
+    must come out bit for bit the same, through auto-resets (49 152 envs x 40 steps)."""
+    n, steps = 49152, 40
+    tiered = make_vec("UR5DynReach-v1", num_envs=n, seed=23)
+    monkeypatch.setenv("URGYM_STEP_TIERS", "0")
+    uniform = make_vec("UR5DynReach-v1", num_envs=n, seed=23)
+    for e in (tiered, uniform):
+        e.reset(seed=23)
+    gen = torch.Generator(device="cuda").manual_seed(23)
+    for t in range(steps):
+        a = torch.rand((n, 6), device="cuda", generator=gen) * 2 - 1
+        tiered.step(a)
+        uniform.step(a)
+        if t % 8 == 7 or t == steps - 1:
+            torch.cuda.synchronize()
+            for k in ("observation", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success", "collision", "status"):
+                assert torch.equal(tiered.buf[k], uniform.buf[k]), (k, t)
+            for k in STATE:
+                assert torch.equal(tiered.buf[k], uniform.buf[k]), (k, t)
+    assert int(tiered.buf["episode_id"].max()) > 1  # episodes ended and restarted on the way
+    tiered.close()
+    uniform.close()
+
+
 def test_c_abi_error_behaviour_and_streams():
     """Error paths of the C-ABI on a GPU box (bad config, unbound handle, null actions) and stream semantics: two
     handles driven on two non-default streams give the same results as on the default stream."""
