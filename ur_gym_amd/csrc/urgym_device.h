@@ -454,7 +454,9 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   // plane tests of the tetrahedron all use them (a slot at or beyond r.n holds stale data and is masked where it matters)
   const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
   {
-    const bool in = ((r.n > 0) & (len2(W0 - w) <= 1e-12)) | ((r.n > 1) & (len2(W1 - w) <= 1e-12)) | ((r.n > 2) & (len2(W2 - w) <= 1e-12));
+    // (bitwise on purpose: three independent comparisons, no short-circuit branches)
+    const bool in = (((int)(r.n > 0) & (int)(len2(W0 - w) <= 1e-12)) | ((int)(r.n > 1) & (int)(len2(W1 - w) <= 1e-12)) |
+                     ((int)(r.n > 2) & (int)(len2(W2 - w) <= 1e-12))) != 0;
     if (in) { gjk_finish(r, true, 1); return; }
   }
   const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;

@@ -1005,6 +1005,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
 #endif
     STAMP_TIME(4);
     STAMP(5, (unsigned long long)trips | ((unsigned long long)draws << 32));
+    (void)trips; (void)draws;  // (diagnostic counters of the stamps build)
     // ---- EPA: penetration depth of the marked queries, one wave per query (urgym_device.h epa_wave).  A wave that has left
     //      the pool turns into a service wave: it keeps looking for marks and serves them while the other waves still iterate
     //      (overlapping cores are found within a few GJK iterations, an EPA takes 70-250 us: starting it at once instead of
