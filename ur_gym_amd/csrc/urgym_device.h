@@ -374,7 +374,7 @@ __device__ __forceinline__ D3 tri_closest(D3 a, D3 b, D3 c, int& mask) {
   return a + ab * (vb * den) + ac * (vc * den);
 }
 
-enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4 };
+enum { GJK_PENETRATING = 1, GJK_ITERCAP = 2, GJK_SEPARATED = 4, GJK_CLOSE = 8 /* stopped by the upper bound of a verdict query */ };
 
 // Closest distance between the CORE shapes A (posed by T = pose of A in B's frame) and B (canonical frame):
 // the same algorithm the reference reaches through p.getClosestPoints (pyb_setup.py:401-452), i.e. Bullet's
@@ -438,7 +438,12 @@ __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int de
 }
 // one iteration of btGjkPairDetector's loop.  max_d: Bullet's early-out distance of this query (handed in per call rather than
 // kept in the run: callers derive it from the query's kind, which costs less than two VGPRs across the loop)
-__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d) {
+// verdict_d (0 = off): for a query that only asks "are the cores closer than verdict_d?".  |v| is the distance of a point of A - B from
+// the origin, i.e. an UPPER bound of the core distance: once it is <= verdict_d the answer is yes whatever the search would still
+// find, and the search stops there (Bullet converges first and compares then -- same verdict).  The matching lower bound is the
+// early-out above: such a caller hands in max_d = verdict_d.
+__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d,
+                                            double verdict_d = 0.0) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
   D3 w;
@@ -557,6 +562,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   if (!valid) { gjk_finish(r, true, 3); return; }
   const double nsq = len2(nv);
   if (nsq < REL_ERROR2) { r.v = nv; gjk_finish(r, true, 6); return; }
+  if (nsq <= verdict_d * verdict_d) { r.v = nv; r.info |= GJK_CLOSE; gjk_finish(r, true, 14); return; }
   const double prev = r.sq;
   r.sq = nsq;
   if (prev - nsq <= EPS * prev) { gjk_finish(r, true, 12); return; }

@@ -944,7 +944,12 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       trips_self += (__ballot(busy && kind == Q_SELF) != 0ull) ? 1 : 0;
 #endif
       if (busy) {
-        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), margin_sum() + 0.02 + ((kind == 3 || exact) ? 5.0 : cfg.collision_margin));
+        // exact queries (link distances): Bullet's early-out distance of getClosestPoints(distance = 5.0).  Boolean queries ("closer
+        // than the contact margin?", check_collision): both bounds of the search are compared with the margin itself -- the search
+        // stops as soon as either decides, with the verdict Bullet reaches after converging (pyb_setup.py:402-422)
+        const bool wants_distance = (kind == 3 || exact);
+        const double verdict_d = wants_distance ? 0.0 : margin_sum() + cfg.collision_margin;
+        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d);
         SECTION(3);
         if (run.done) {
           const double msum = margin_sum();
@@ -960,7 +965,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
             if (workbench) atomicMin(reinterpret_cast<long long*>(dist_cell(lb - 2, e)), sortable(dist));
             else *dist_cell(lb - 2, e) = dist;
           } else {
-            const bool hit = (run.info & GJK_PENETRATING) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
+            const bool hit = (run.info & (GJK_PENETRATING | GJK_CLOSE)) || (!(run.info & GJK_SEPARATED) && (run.core - msum) <= cfg.collision_margin);
             if (hit) atomicOr(&s_flags[e], COLL_BIT);
           }
           busy = false;
