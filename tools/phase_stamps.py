@@ -78,6 +78,15 @@ if not args.reset_kernel:
           f"trips that carried a link <-> link query: {100.0 * trips_self.sum() / trips.sum():.1f} %")
     for i, nm in enumerate(names):
         print(f"    {nm:48s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
+if not args.reset_kernel:
+    loop_end = st[:, :, 4] - st[:, :, 0].min(axis=1, keepdims=True)   # end of each wave's loop since its workgroup started
+    last = loop_end.argmax(axis=1)
+    print("  wave whose loop ends last (share of workgroups):", ", ".join(f"wave {w}: {100.0 * (last == w).mean():.0f} %" for w in range(W)),
+          "| mean loop end per wave (us):", ", ".join(f"{us(loop_end[:, w].mean()):.0f}" for w in range(W)),
+          "| trips per wave index:", ", ".join(f"{trips[:, w].mean():.1f}" for w in range(W)))
+    slow = np.argsort(loop_end.max(axis=1))[-max(1, blocks // 20):]      # the slowest 5 % of the workgroups
+    print("  slowest 5 % of the workgroups: last wave", ", ".join(f"{w}: {100.0 * (last[slow] == w).mean():.0f} %" for w in range(W)),
+          f"| its trips mean {trips[slow, last[slow]].mean():.1f}, its loop end mean {us(loop_end[slow].max(axis=1).mean()):.0f} us")
 blk = st[:, :, 7].max(axis=1) - st[:, :, 0].min(axis=1)
 print(f"  block lifetime: mean {us(blk.mean()):.1f} us, max {us(blk.max()):.1f} us; kernel span {us(st[:, :, 7].max() - st[:, :, 0].min()):.1f} us")
 
