@@ -1,6 +1,8 @@
 // urgym_hip.hip — fused UR5e reach environment kernels for MI355X (gfx950) + the C-ABI of include/urgym.h.
 //
-// One kernel template env_kernel<KIND, MODE> (MODE = STEP | RESET | REFRESH | PREFETCH); device math in urgym_device.h.
+// One body template env_body<KIND, MODE> (MODE = STEP | RESET | REFRESH | PREFETCH) behind env_kernel<KIND, MODE> (one mode per launch)
+// and env_step_fused<KIND> (the steady-state step: STEP workgroups + the PREFETCH refill of the previous step); device math in
+// urgym_device.h.
 // One workgroup = 4 waves (256 lanes) serving E environments (a launch parameter urgym_create picks: up to 128 for STEP, so that
 // N = 65536 is ONE round of resident workgroups; up to 64 for RESET / REFRESH, 32 for PREFETCH).
 //
@@ -12,8 +14,9 @@
 //        memory (joint_of_step, obstacle_of_step) until P1 has published, and reads the cache afterwards.
 //   pool the closest-distance work of the workgroup: 5 E obstacle "tickets" (exact distance hull(link) <-> cylinder,
 //        pyb_setup.py:439-456; 15 E with URGYM_LINK_DIST_WORKBENCH: table and track too) + the set bits of the pair masks
-//        (boolean "closer than the margin?" queries).  Every lane advances ITS query by one GJK iteration per loop trip
-//        through one inlined, resumable GJK body (gjk_begin / gjk_iterate); idle lanes draw the next item together.
+//        (boolean "closer than the margin?" queries, which stop as soon as the upper or the lower bound of the running search
+//        decides the verdict).  Every lane advances ITS query by one GJK iteration per loop trip through one inlined, resumable
+//        GJK body (gjk_begin / gjk_iterate); idle lanes draw the next item together.
 //   EPA  the (rare) obstacle queries whose cores overlap and whose distance is consumed: penetration depth by an expanding
 //        polytope, one wave per query, faces spread over the lanes (pyb_setup.py:452 stores a negative contact distance);
 //        served by waves that have left the pool while the others still iterate.
