@@ -772,10 +772,10 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
 
 // convenience wrapper: run one query to the end
 __device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
-                                                    D3 v0, double max_d, int& info) {
+                                                    D3 v0, double max_d, int& info, double verdict_d = 0.0) {
   GjkRun r;
   gjk_begin(r, v0);
-  while (!r.done) gjk_iterate(r, g, A, T, B, max_d);
+  while (!r.done) gjk_iterate(r, g, A, T, B, max_d, verdict_d);
   info = r.info;
   return r.core;
 }

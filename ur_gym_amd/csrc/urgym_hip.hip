@@ -378,7 +378,11 @@ __device__ bool sample_attempt(const KParams& P, XRef slot, int n, uint32_t epis
       int info;
       // Bullet's pair detector starts from the world +Y axis; B's frame is the obstacle's
       store(slot, rel(To, Tt));
-      double core = gjk_core_distance(P.graph, ta, slot, cyl_desc(), rotT(To, d3(0, 1, 0)), msum + 0.02 + 5.0, info);
+      // Only the verdict "closer than the clearance?" is asked (reach.py:322, 675), so the search stops as soon as one of its bounds
+      // decides: the support-plane distance above the limit -> clear (the returned |v| is larger still), |v| below it -> too close.
+      // (the upper bound is taken a hair inside the limit, so that "<" of the reference holds for the value returned)
+      const double limit = msum + cfg.target_clearance;
+      double core = gjk_core_distance(P.graph, ta, slot, cyl_desc(), rotT(To, d3(0, 1, 0)), limit, info, limit * (1.0 - 1.0e-12));
       double dist = (info & GJK_PENETRATING) ? -msum : core - msum;
       fail = dist < cfg.target_clearance;
     }
