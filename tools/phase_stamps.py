@@ -38,7 +38,7 @@ if args.tiers:
 if args.reset_kernel:
     groups = int(os.environ.get('URGYM_RESET_ENVS', '4'))
     blocks = 2048  # upper bound; only the workgroups of the LAST launch are kept below
-W, S = int(os.environ.get("URGYM_WAVES", "4")), 20
+W, S = int(os.environ.get("URGYM_WAVES", "4")), 44
 buf = np.zeros(blocks * W * S, dtype=np.uint64)
 lib = env.lib
 lib.urgym_debug_stamps.argtypes = [C.c_void_p, C.c_int]
@@ -67,17 +67,41 @@ loop = (st[:, :, 4] - st[:, :, 3])
 print(f"  loop trips per wave: mean {trips.mean():.1f} max {trips.max()}   draws per wave: mean {draws.mean():.1f}")
 print(f"  time per loop trip: {us(loop.sum()) / trips.sum():.2f} us")
 if not args.reset_kernel:
-    sect = st[:, :, 12:18].astype(np.float64)
+    sect = np.concatenate([st[:, :, 12:18], st[:, :, 20:24]], axis=2).astype(np.float64)
     # section i ends at mark i (urgym_device.h URGYM_TRIP_MARK / the kernel's SECTION): 0 is never marked
     names = ("(unused)", "support of A (pose transform, hull climb)", "support of B, exits, simplex vertex stored",
-             "simplex: closest point, reduction, convergence tests", "result handling", "polling, draw, set-up")
+             "vertex reduction, convergence tests", "result handling", "polling, draw, set-up",
+             "simplex front: segment case / plane tests", "simplex: face evaluations (triangle routine)", "(unused)", "(unused)")
     tot = sect.sum()
     print("  wave time inside the loop by section (microseconds per trip; share):")
     boxq, selfq, trips_self = (st[:, :, 18] & 0xFFFFFFFF), (st[:, :, 18] >> 32), st[:, :, 19]
     print(f"  pair queries per workgroup: {boxq.sum(axis=1).mean():.1f} link <-> table / track, {selfq.sum(axis=1).mean():.1f} link <-> link; "
           f"trips that carried a link <-> link query: {100.0 * trips_self.sum() / trips.sum():.1f} %")
-    for i, nm in enumerate(names):
-        print(f"    {nm:48s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
+    for i in (1, 2, 6, 7, 3, 4, 5):
+        print(f"    {names[i]:52s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
+    # lane counters: (executions by the wave, active lanes summed over them)
+    cn = ("loop trip (lanes = busy lanes)", "hull climb: record round", "hull climb: chained record", "simplex: segment case",
+          "simplex: four plane tests (tetrahedron)", "simplex: one face evaluation", "  triangle exit: vertex A", "  triangle exit: vertex B",
+          "  triangle exit: edge AB (division)", "  triangle exit: vertex C", "  triangle exit: edge AC (division)", "  triangle exit: edge BC (division)",
+          "  triangle exit: face interior (division)", "vertex reduction", "draw + set-up", "result handling of a finished query",
+          "cylinder support (sqrt + division)", "box support", "early exits (separating axis / duplicate / no progress)", "(unused)")
+    cnt = st[:, :, 24:44]
+    ex = (cnt & 0xFFFFFFFF).astype(np.float64).sum(axis=(0, 1)); ln = (cnt >> 32).astype(np.float64).sum(axis=(0, 1))
+    T = float(trips.sum())
+    busy = ln[0] / max(ex[0], 1.0)
+    print(f"  LANE TABLE (all waves of the last launch; a wave instruction is issued for 64 lanes whatever the exec mask holds)")
+    print(f"    busy lanes per loop trip: {busy:.1f} of 64 = {100 * busy / 64:.1f} %   (idle-lane term: {100 * (1 - busy / 64):.1f} % of every issued lane is an idle lane)")
+    print(f"    {'code':58s} {'executions per trip':>20s} {'active lanes per execution':>28s} {'of the busy lanes':>18s}")
+    for i, nm in enumerate(cn[:19]):
+        if ex[i] <= 0: continue
+        a = ln[i] / ex[i]
+        print(f"    {nm:58s} {ex[i] / T:20.2f} {a:28.1f} {100 * a / max(busy, 1e-9):17.1f} %")
+    # time-weighted occupancy of the issued lanes: each section's time weighted with the lanes active in its dominant code
+    occ = {1: ln[1] / max(ex[1], 1), 2: busy, 6: (ln[3] + ln[4]) / max(ex[3] + ex[4], 1), 7: (ln[6:13].sum() + ln[5]) / max(ex[6:13].sum() + ex[5], 1), 3: ln[13] / max(ex[13], 1),
+           4: busy, 5: busy}
+    tw = sum(sect[:, :, i].sum() * occ[i] / 64.0 for i in occ) / sum(sect[:, :, i].sum() for i in occ)
+    print(f"    time-weighted share of active lanes over the loop (section time x lanes active in its dominant code): {100 * tw:.1f} %"
+          f"  -> idle lanes {100 * (1 - busy / 64):.1f} %, divergence among the busy lanes {100 * (1 - tw / (busy / 64)):.1f} %")
 if not args.reset_kernel:
     loop_end = st[:, :, 4] - st[:, :, 0].min(axis=1, keepdims=True)   # end of each wave's loop since its workgroup started
     last = loop_end.argmax(axis=1)

@@ -20,18 +20,43 @@ using std::fma; using std::sqrt; using std::fabs; using std::fmin; using std::fm
 #define URGYM_LDS __attribute__((address_space(3)))
 #endif
 
-// diagnostic hook (-DURGYM_STAMPS build of urgym_hip.hip, tools/phase_stamps.py): cycles per section of a GJK iteration, summed
-// in a per-wave LDS clock (clk[0] = last mark, clk[1 + i] = cycles of section i).  Nothing of it is compiled into the product.
+// diagnostic hook (-DURGYM_STAMPS build of urgym_hip.hip, tools/phase_stamps.py): a per-wave profile in LDS.  prof[0] = last mark,
+// prof[1 + i] = cycles of section i (a section ends at its mark); from prof[1 + PROF_SECTIONS] on, as uint32 pairs, counter c =
+// (times the wave executed the marked code, lanes that were active there summed over those executions): how full the wave was
+// wherever it went.  Nothing of it is compiled into the product.
 #if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+constexpr int PROF_SECTIONS = 10, PROF_COUNTERS = 20, PROF_WORDS = 1 + PROF_SECTIONS + PROF_COUNTERS;
+// counters: 0 loop trip (lanes = busy lanes), 1 record round of the hull climb, 2 chained record of a round, 3 segment case,
+// 4 plane tests of the tetrahedron, 5 one face evaluation (triangle routine), 6..12 exits of the triangle routine (vertex A, B, edge
+// AB, vertex C, edge AC, edge BC, face interior), 13 vertex reduction, 14 draw + set-up, 15 result handling of a finished query,
+// 16 cylinder support, 17 box support, 18 early exits of the iteration (separating axis / duplicate / no progress)
 #define URGYM_TRIP_MARK(i) trip_mark(r.clk, i)
+#define URGYM_LANE_MARK(c) lane_mark(r.clk, c)
+#define URGYM_LANE_MARK_AT(clk, c) lane_mark(clk, c)
+#define URGYM_PROF_PARAM , URGYM_LDS unsigned long long* clk
+#define URGYM_PROF_PASS(x) , x
 __device__ __forceinline__ void trip_mark(URGYM_LDS unsigned long long* clk, int i) {
   if (clk == nullptr) return;  // a search outside the instrumented loop
   const unsigned long long t = __builtin_amdgcn_s_memtime();
   clk[1 + i] += t - clk[0];
   clk[0] = t;
 }
+__device__ __forceinline__ void lane_mark(URGYM_LDS unsigned long long* clk, int c) {
+  if (clk == nullptr) return;
+  const unsigned long long m = __ballot(1);  // the lanes that execute this very code
+  const int me = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  if (me == __builtin_ctzll(m)) {
+    URGYM_LDS unsigned int* w = (URGYM_LDS unsigned int*)(clk + 1 + PROF_SECTIONS) + 2 * c;
+    w[0] += 1u;
+    w[1] += (unsigned int)__popcll(m);
+  }
+}
 #else
 #define URGYM_TRIP_MARK(i) do {} while (0)
+#define URGYM_LANE_MARK(c) do {} while (0)
+#define URGYM_LANE_MARK_AT(clk, c) do {} while (0)
+#define URGYM_PROF_PARAM
+#define URGYM_PROF_PASS(x)
 #endif
 
 namespace urgym {
@@ -313,13 +338,15 @@ __device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, co
 // the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph).  The start comes
 // from the direction map; one climbing step = one round trip: the whole 224-byte record of the current vertex at once
 // (the vertex itself is one of its entries, so a round ranks it together with its neighbours).
-__device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d) {
+__device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d URGYM_PROF_PARAM) {
   int cur = g.dirmap[h * DIRMAP_CELLS + dirmap_cell(d)];
   for (;;) {
     int nxt = cur;
     int rec = cur;
     double best = -1.0e300;
+    URGYM_LANE_MARK_AT(clk, 1);
     do {
+      if (rec != cur) URGYM_LANE_MARK_AT(clk, 2);
       const NbrRec& R = g.recs[rec];
       const int nextrec = R.next;
       const U8 id = R.id;  // header + ids travel with the first half's coordinates
@@ -334,10 +361,11 @@ __device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d
   return d3(p[0], p[1], p[2]);
 }
 
-__device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d) {
+__device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d URGYM_PROF_PARAM) {
   if (s.type == SH_HULL) {
-    return hull_support_climb(g, s.hull, d);
+    return hull_support_climb(g, s.hull, d URGYM_PROF_PASS(clk));
   } else if (s.type == SH_CYLZ) {
+    URGYM_LANE_MARK_AT(clk, 16);
     double sn = sqrt(d.x * d.x + d.y * d.y);
     double hz = d.z < 0.0 ? -s.hz : s.hz;
     if (sn != 0.0) {
@@ -346,29 +374,32 @@ __device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc&
     }
     return d3(s.hx, 0.0, hz);
   } else if (s.type == SH_BOX) {
+    URGYM_LANE_MARK_AT(clk, 17);
     return d3(d.x >= 0.0 ? s.hx : -s.hx, d.y >= 0.0 ? s.hy : -s.hy, d.z >= 0.0 ? s.hz : -s.hz);
   }
   return d3(0.0, 0.0, 0.0);
 }
 
 // closest point of triangle (a,b,c) to the origin (Voronoi-region tests, Ericson RTCD §5.1.5); mask bit i = vertex i used
-__device__ __forceinline__ D3 tri_closest(D3 a, D3 b, D3 c, int& mask) {
+__device__ __forceinline__ D3 tri_closest(D3 a, D3 b, D3 c, int& mask URGYM_PROF_PARAM) {
   D3 ab = b - a, ac = c - a;
   double d1 = -dot(ab, a), d2 = -dot(ac, a);
-  if (d1 <= 0.0 && d2 <= 0.0) { mask = 1; return a; }
+  if (d1 <= 0.0 && d2 <= 0.0) { URGYM_LANE_MARK_AT(clk, 6); mask = 1; return a; }
   double d3_ = -dot(ab, b), d4 = -dot(ac, b);
-  if (d3_ >= 0.0 && d4 <= d3_) { mask = 2; return b; }
+  if (d3_ >= 0.0 && d4 <= d3_) { URGYM_LANE_MARK_AT(clk, 7); mask = 2; return b; }
   double vc = d1 * d4 - d3_ * d2;
-  if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) { mask = 3; return a + ab * (d1 / (d1 - d3_)); }
+  if (vc <= 0.0 && d1 >= 0.0 && d3_ <= 0.0) { URGYM_LANE_MARK_AT(clk, 8); mask = 3; return a + ab * (d1 / (d1 - d3_)); }
   double d5 = -dot(ab, c), d6 = -dot(ac, c);
-  if (d6 >= 0.0 && d5 <= d6) { mask = 4; return c; }
+  if (d6 >= 0.0 && d5 <= d6) { URGYM_LANE_MARK_AT(clk, 9); mask = 4; return c; }
   double vb = d5 * d2 - d1 * d6;
-  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { mask = 5; return a + ac * (d2 / (d2 - d6)); }
+  if (vb <= 0.0 && d2 >= 0.0 && d6 <= 0.0) { URGYM_LANE_MARK_AT(clk, 10); mask = 5; return a + ac * (d2 / (d2 - d6)); }
   double va = d3_ * d6 - d5 * d4;
   if (va <= 0.0 && (d4 - d3_) >= 0.0 && (d5 - d6) >= 0.0) {
+    URGYM_LANE_MARK_AT(clk, 11);
     mask = 6;
     return b + (c - b) * ((d4 - d3_) / ((d4 - d3_) + (d5 - d6)));
   }
+  URGYM_LANE_MARK_AT(clk, 12);
   double den = 1.0 / (va + vb + vc);
   mask = 7;
   return a + ab * (vb * den) + ac * (vc * den);
@@ -448,13 +479,13 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
   const double EPS = 2.220446049250313e-16;
   D3 w;
   {
-    D3 p = apply(T, support_local(g, A, rotT(T, -r.v)));
+    D3 p = apply(T, support_local(g, A, rotT(T, -r.v) URGYM_PROF_PASS(r.clk)));
     URGYM_TRIP_MARK(1);
-    D3 q = support_local(g, B, r.v);
+    D3 q = support_local(g, B, r.v URGYM_PROF_PASS(r.clk));
     w = p - q;
   }
   const double delta = dot(r.v, w);
-  if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { gjk_finish(r, true, 10); return; }
+  if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { URGYM_LANE_MARK(18); gjk_finish(r, true, 10); return; }
   // the (up to three) vertices already in the simplex: read once, together -- the duplicate test below, the segment case and the
   // plane tests of the tetrahedron all use them (a slot at or beyond r.n holds stale data and is masked where it matters)
   const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
@@ -462,10 +493,10 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     // (bitwise on purpose: three independent comparisons, no short-circuit branches)
     const bool in = (((int)(r.n > 0) & (int)(len2(W0 - w) <= 1e-12)) | ((int)(r.n > 1) & (int)(len2(W1 - w) <= 1e-12)) |
                      ((int)(r.n > 2) & (int)(len2(W2 - w) <= 1e-12))) != 0;
-    if (in) { gjk_finish(r, true, 1); return; }
+    if (in) { URGYM_LANE_MARK(18); gjk_finish(r, true, 1); return; }
   }
   const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;
-  if (f0 <= f1) { gjk_finish(r, true, (f0 <= 0.0) ? 2 : 11); return; }
+  if (f0 <= f1) { URGYM_LANE_MARK(18); gjk_finish(r, true, (f0 <= 0.0) ? 2 : 11); return; }
   stw(T, r.n, w);
   int n = r.n + 1;
   URGYM_TRIP_MARK(2);
@@ -478,6 +509,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
     nv = w;
     reduce = false;
   } else if (n == 2) {
+    URGYM_LANE_MARK(3);
     D3 s0 = W0;
     D3 e = w - s0;
     double t = -dot(e, s0);
@@ -510,6 +542,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
       // the four plane tests as straight-line code on the vertices read above: four independent chains the scheduler can
       // interleave, instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
       todo = 0;
+      URGYM_LANE_MARK(4);
       auto plane = [&](D3 a, D3 b, D3 c, D3 o, int bit) {
         const D3 nrm = cross(b - a, c - a);
         const double signp = -dot(a, nrm), signd = dot(o - a, nrm);
@@ -521,6 +554,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
       plane(W0, w, W1, W2, 4);   // ADB | C
       plane(W1, w, W2, W0, 8);   // BDC | A
     }
+    URGYM_TRIP_MARK(6);
     double best = 1.0e300;
     bool any_out = false;
     ua = ub = uc = ud = false;
@@ -532,7 +566,8 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
       face_vertices(f, ia, ib, ic, io);
       const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
       int m3;
-      const D3 pt = tri_closest(a, b, c, m3);
+      URGYM_LANE_MARK(5);
+      const D3 pt = tri_closest(a, b, c, m3 URGYM_PROF_PASS(r.clk));
       const double l = len2(pt);
       if (!any_out || l < best) {
         best = l;
@@ -550,8 +585,9 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const
       reduce = false;
     }
   }
-  URGYM_TRIP_MARK(3);
+  URGYM_TRIP_MARK(7);
   if (reduce) {
+    URGYM_LANE_MARK(13);
     // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
     if (n >= 4 && !ud) { n--; }
     if (n >= 3 && !uc) { n--; stw(T, 2, ldw(T, n)); }
@@ -631,7 +667,7 @@ __device__ __forceinline__ bool epa_plane(D3 pi, D3 pj, D3 pk, D3& n, double& d)
 // T: pose of A in B's frame, stored at M[0..11][0] of `ws` (XRef{ws.base, ws.stride}).  Returns depth(cores) >= 0.
 __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const ShapeDesc& B, EpaWs ws, int lane, bool& capped) {
   const XRef T{ws.base, ws.stride};
-  auto supp = [&](D3 n) -> D3 { return apply(T, support_local(g, A, rotT(T, n))) - support_local(g, B, -n); };
+  auto supp = [&](D3 n) -> D3 { return apply(T, support_local(g, A, rotT(T, n) URGYM_PROF_PASS(nullptr))) - support_local(g, B, -n URGYM_PROF_PASS(nullptr)); };
   const double t = 0.5773502691896258;
   {
     const D3 p0 = supp(d3(t, t, t)), p1 = supp(d3(t, -t, -t)), p2 = supp(d3(-t, t, -t)), p3 = supp(d3(-t, -t, t));

@@ -65,6 +65,11 @@ constexpr uint32_t NO_ITEM = 0xFFFFFFFFu;
 #define URGYM_REFILL_MIN 16
 #endif
 constexpr int REFILL_MIN = URGYM_REFILL_MIN;
+// Resident STEP workgroups per CU the kernels are compiled for (launch bounds -> VGPR budget: 3 -> 168, 2 -> 256).  3 is the product;
+// 2 exists to MEASURE the register-rich variant (profiles/r3/EXPERIMENTS.md), it is not shipped.
+#ifndef URGYM_RESIDENT
+#define URGYM_RESIDENT 3
+#endif
 constexpr int SC_FRAMES = 19, SC_FIELDS = SC_FRAMES + 72;  // rows of KParams::sc_scratch
 // bits of the per-env culling mask: table vs links 2..6, track vs links 2..6, the nine self pairs
 constexpr int PAIR_TABLE = 0, PAIR_TRACK = 5, PAIR_SELF = 10;
@@ -512,7 +517,7 @@ __device__ __forceinline__ void obstacle_of_step(const KParams& P, int n, double
 #ifndef URGYM_STAMP_MODE
 #define URGYM_STAMP_MODE 0  /* MODE_STEP; 1 = the auto-reset kernel */
 #endif
-constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 20;  // 0..11 phases (tools/phase_stamps.py), 12..19 cycles per section of the loop
+constexpr int STAMP_BLOCKS = 8192, STAMP_SLOTS = 44;  // 0..11 phases (tools/phase_stamps.py), 12..17 + 20..23 cycles per section of the loop, 24..43 lane counters
 __device__ unsigned long long g_stamps[STAMP_BLOCKS * WAVES * STAMP_SLOTS];
 #define STAMP(k, v)                                                                                         \
   do {                                                                                                      \
@@ -553,7 +558,7 @@ struct EnvLds {
   // ... and per-lane slots
   double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
 #ifdef URGYM_STAMPS
-  unsigned long long s_clk[WAVES][8];        // diagnostic build: per-wave section clock of the loop
+  unsigned long long s_clk[WAVES][PROF_WORDS];  // diagnostic build: per-wave profile of the loop (urgym_device.h: section clock + lane counters)
 #endif
 };
 
@@ -935,7 +940,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     // reduction + convergence tests, 4 result handling, 5 polling + draw + set-up (a mark that no lane of a trip reaches adds its
     // time to the next section)
     URGYM_LDS unsigned long long* clk = (URGYM_LDS unsigned long long*)&L.s_clk[wv][0];
-    if (lane < 8) clk[lane] = 0;
+    if (lane < PROF_WORDS) clk[lane] = 0;
     if (busy) run.clk = clk;
     clk[0] = __builtin_amdgcn_s_memtime();
 #define SECTION(i) trip_mark(clk, i)
@@ -949,6 +954,8 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       trips++;
 #ifdef URGYM_STAMPS
       trips_self += (__ballot(busy && kind == Q_SELF) != 0ull) ? 1 : 0;
+      if (busy) lane_mark(clk, 0);
+      else if (__ballot(busy) == 0ull && lane == 0) { URGYM_LDS unsigned int* w = (URGYM_LDS unsigned int*)(clk + 1 + PROF_SECTIONS); w[0] += 1u; }  // a trip nobody is busy in
 #endif
       if (busy) {
         // exact queries (link distances): Bullet's early-out distance of getClosestPoints(distance = 5.0).  Boolean queries ("closer
@@ -959,6 +966,9 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d);
         SECTION(3);
         if (run.done) {
+#ifdef URGYM_STAMPS
+          lane_mark(clk, 15);
+#endif
           const double msum = margin_sum();
           if (kind == 3 || exact) {
             double dist = run.core - msum;
@@ -997,6 +1007,9 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         }
         if (item != NO_ITEM) {
           draws++;  // (diagnostic: the draws of the lane that reports the stamps)
+#ifdef URGYM_STAMPS
+          lane_mark(clk, 14);
+#endif
           busy = setup(item);
           if (busy) gjk_begin(run, v0);
 #ifdef URGYM_STAMPS
@@ -1012,6 +1025,8 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     }
 #ifdef URGYM_STAMPS
     for (int i = 0; i < 6; i++) STAMP(12 + i, clk[1 + i]);
+    for (int i = 6; i < PROF_SECTIONS; i++) STAMP(20 + i - 6, clk[1 + i]);
+    for (int i = 0; i < PROF_COUNTERS; i++) STAMP(24 + i, clk[1 + PROF_SECTIONS + i]);
     STAMP(18, n_boxq | (n_selfq << 32));
     STAMP(19, trips_self);
 #endif
@@ -1408,7 +1423,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
 }
 
 template <int KIND, int MODE, bool WITH_EPA>
-__global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? 3 : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
+__global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_PREFETCH) ? URGYM_RESIDENT : 2)) env_kernel(const KParams P, const float* __restrict__ actions) {
   __shared__ EnvLds<MODE> lds;
   env_body<KIND, MODE, WITH_EPA>(P, actions, lds, (int)blockIdx.x, (int)gridDim.x);
 }
@@ -1419,7 +1434,7 @@ __global__ void __launch_bounds__(THREADS, ((MODE == MODE_STEP || MODE == MODE_P
 // the slots the step workgroups free in the tail of the launch.  The two kinds never touch the same data (the refill writes record
 // slots the concurrent step cannot read -- episode parity -- and reads nothing the step writes: the episode id travels in its list).
 template <int KIND, bool WITH_EPA>
-__global__ void __launch_bounds__(THREADS, 3) env_step_fused(const KParams Ps, const KParams Pr, const float* __restrict__ actions, const int step_blocks) {
+__global__ void __launch_bounds__(THREADS, URGYM_RESIDENT) env_step_fused(const KParams Ps, const KParams Pr, const float* __restrict__ actions, const int step_blocks) {
   __shared__ union FusedLds {
     EnvLds<MODE_STEP> step;
     EnvLds<MODE_PREFETCH> refill;
@@ -1949,6 +1964,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP, false>, THREADS, 0); break;
     }
     if (oe != hipSuccess || per_cu < 1) per_cu = 3;
+    if (per_cu > URGYM_RESIDENT) per_cu = URGYM_RESIDENT;
     long slots = (long)cus * per_cu;
     const long n = cfg->num_envs;
     // prefetched episode records (below): the refill of ~2 % of the envs runs beside the step kernel, 32 envs per workgroup
