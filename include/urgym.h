@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define URGYM_ABI_VERSION 2
+#define URGYM_ABI_VERSION 3
 
 /* env kinds = the reference's registered ids (UR_gym/__init__.py:19-42, UR_gym/envs/ur_tasks.py:37-90) */
 enum {
@@ -128,7 +128,8 @@ typedef struct urgym_buffers {
   double* obst_vel;   /* [9][N] rows 0..5: per-episode twist (v, omega) that set_velocity (reach.py:728-753) re-applies while
                          step_count < dyn_motion_steps; rows 6..8: the base displacement that twist produces in ONE env step
                          (20 Bullet sub-steps in which the linear velocity drifts by h * omega x v) --
-                         derived at reset / refresh; a caller that edits rows 0..5 must call urgym_refresh */
+                         derived at reset / refresh; a caller that writes a twist of its own into rows 0..5 calls
+                         urgym_derive_obstacle_motion afterwards (urgym_refresh would recompute the twist from start / end) */
   double* link_dist;  /* [5][N] task.link_dist == task.last_dist (reach.py:680-681,780-782) */
   int32_t* step_count;/* [N] ReachDyn.step_num == TimeLimit._elapsed_steps */
   int32_t* episode_id;/* [N] number of resets so far (RNG counter) */
@@ -194,8 +195,16 @@ int urgym_refresh(void* handle, const uint8_t* mask_dev, void* stream);
 
 /* The caller has edited episode_id (or step_count) of some envs in the bound buffers: the episode records the library keeps ready
  * for the inline auto-reset may no longer match, so the next max_episode_steps + 1 steps carry the fallback
- * launches that reset such envs with a kernel.  Not needed after urgym_bind / urgym_reset (they do it themselves); cheap. */
+ * launches that reset such envs with a kernel.  Every record and every pending refill entry is discarded (each env takes the
+ * fallback at its first finish and leaves it with fresh records), after a device synchronisation: call it between steps, like the
+ * edit itself.  Not needed after urgym_bind / urgym_reset (they do it themselves). */
 int urgym_invalidate_records(void* handle);
+
+/* The caller has written an obstacle twist of its own into rows 0..5 of obst_vel (a set_state-style harness; the reference's
+ * counterpart is assigning task.velocity before sim.step, reach.py:745-747): re-derives rows 6..8 -- the base displacement of one
+ * env step under that twist (pyb_setup.py:52-55, 20 sub-steps) -- for every env.  Leaves everything else alone (urgym_refresh would
+ * teleport the obstacle to obst_start and recompute the twist from start / end).  No-op for UR5OriReach-v1. */
+int urgym_derive_obstacle_motion(void* handle, void* stream);
 
 /* Unit probe of the device closest-distance routine (what p.getClosestPoints computes, pyb_setup.py:401-452): one query per
  * entry, all pointers are DEVICE pointers.  type: 0 hull (par[0] = PyBullet link 1..6), 1 cylinder-Z (radius, height),

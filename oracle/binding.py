@@ -102,8 +102,16 @@ class OracleEnv:
 
     def load_state(self, state):
         """Copy arrays (same names as the buffers) into the oracle's buffers."""
+        derive = False
         for k, v in state.items():
-            self.buf[k][...] = np.asarray(v).reshape(self.buf[k].shape)
+            v = np.asarray(v)
+            if k == "obst_vel" and v.shape[0] == 6:  # a twist only: rows 6..8 (displacement per env step) are derived from it
+                self.buf[k][:6] = v.reshape(6, self.num_envs)
+                derive = True
+            else:
+                self.buf[k][...] = v.reshape(self.buf[k].shape)
+        if derive:
+            assert lib().urgym_oracle_derive_obstacle_motion(self._h) == 0
 
     def reset(self, seed=_abi.KEEP_SEED, mask=None):
         m = None if mask is None else np.ascontiguousarray(mask, dtype=np.uint8)

@@ -1317,6 +1317,19 @@ int urgym_oracle_refresh(void* h, const uint8_t* mask, int threads) {
   });
   return URGYM_OK;
 }
+// counterpart of urgym_derive_obstacle_motion (include/urgym.h): rows 6..8 of obst_vel from the twist in rows 0..5
+int urgym_oracle_derive_obstacle_motion(void* h) {
+  Oracle* o = (Oracle*)h;
+  if (!o) return URGYM_ERR_ARG;
+  if (o->cfg.env_kind == URGYM_ENV_ORI) return URGYM_OK;
+  const int N = o->cfg.num_envs;
+  for (int n = 0; n < N; n++) {
+    double vel[6];
+    for (int i = 0; i < 6; i++) vel[i] = S(o->buf.obst_vel, i, n, N);
+    store_velocity(o->cfg, o->buf, n, vel);
+  }
+  return URGYM_OK;
+}
 int urgym_oracle_step(void* h, const float* actions, int threads) {
   Oracle* o = (Oracle*)h;
   if (!o || !actions) return URGYM_ERR_ARG;

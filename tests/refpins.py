@@ -66,17 +66,17 @@ def state_before(name, before, link_dist_state):
     st["obst_quat"] = quat.reshape(4, 1)
     st["link_dist"] = np.asarray(link_dist_state, dtype=np.float64).reshape(5, 1)
     start, end = pose.copy(), np.zeros(6)
-    vel9 = np.zeros(9)
+    vel6 = np.zeros(6)  # the twist only: the library derives the displacement per env step from it (urgym_derive_obstacle_motion)
     if name == "dyn":
         # a start/end pair whose ReachDyn.set_velocity twist (reach.py:735-745, time_duration 2) is the stored one
         v = o[sl["velocity"]]
         end[:3] = start[:3] + 2.0 * v[:3]
         r_end = Rot.from_rotvec(2.0 * v[3:]) * Rot.from_quat(quat)
         end[3:] = r_end.as_euler("xyz")
-        vel9[:6] = v
+        vel6[:] = v
     st["obst_start"] = start.reshape(6, 1)
     st["obst_end"] = end.reshape(6, 1)
-    st["obst_vel"] = vel9.reshape(9, 1)
+    st["obst_vel"] = vel6.reshape(6, 1)
     return st
 
 

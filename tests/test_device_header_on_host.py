@@ -1,4 +1,4 @@
-"""The DEVICE closest-distance code (ur_gym_amd/csrc/urgym_device.h: hull graph climb, Voronoi simplex, resumable GJK)
+"""The DEVICE closest-distance code (ur_gym_amd/csrc/urgym_device.h: exact hull support map, Voronoi simplex, resumable GJK)
 compiled with g++ through tests/device_harness.cpp and run on the CPU against the oracle: the logic of the HIP path is
 covered by the `-m "not gpu"` suite as well, not only on the GPU box.  Test infrastructure; nothing here ships."""
 import ctypes as C
@@ -24,7 +24,33 @@ def harness():
     lib = C.CDLL(SO)
     dp = C.POINTER(C.c_double)
     lib.harness_closest.argtypes = [C.c_int, dp, dp, C.c_int, dp, dp, C.c_double, dp]
+    lib.harness_support_census.argtypes = [C.c_int, C.c_int, C.c_ulonglong, C.POINTER(C.c_long)]
+    lib.harness_table_stats.argtypes = [C.POINTER(C.c_long)]
     return lib
+
+
+@pytest.mark.parametrize("mode,count", [(0, 150000), (1, 60000), (2, 20000), (3, 20000), (4, 40000)])
+def test_support_map_returns_the_scans_vertex(harness, mode, count):
+    """The exact support map (candidate vertices per direction cell, urgym_device.h hull_support + urgym_tables_host.h) against the
+    linear scan over the hull's vertices that the oracle runs (first maximum): every direction, every hull, bit for bit -- random
+    directions, directions in which two neighbouring vertices tie, exact face normals (all vertices of a flat face tie) and their
+    1e-9 neighbourhood, and the borders of the cube map's cells and faces (the device picks the cell in float32)."""
+    out = (C.c_long * 3)()
+    assert harness.harness_support_census(mode, count, 12345 + mode, out) == 0
+    bad, tested, visited = out[0], out[1], out[2]
+    assert tested > 0.5 * 6 * count
+    assert bad == 0, (mode, bad, tested)
+    print(f"mode {mode}: {tested} directions, {visited / tested:.3f} records per support call")
+
+
+def test_support_map_shape(harness):
+    """One 128-byte record answers practically every cell: the table's shape is what the kernel's cost model rests on."""
+    out = (C.c_long * 8)()
+    assert harness.harness_table_stats(out) == 0
+    cells = sum(out[:6])
+    assert out[0] / cells > 0.7 and (out[0] + out[1] + out[2] + out[3]) / cells > 0.998
+    assert out[6] < 65536  # a cell's code is 16 bits
+    print("cells by candidates (1, 2, 3, 4, 5..8, > 8):", list(out[:6]), "records:", out[6], "longest list:", out[7])
 
 
 def _pose(rng, lo, hi):
@@ -63,8 +89,8 @@ def test_device_gjk_matches_oracle_on_host(harness, oracle, other):
 def test_exactly_tied_support_values_go_to_the_scans_vertex(harness, oracle):
     """Regression (round 2): near convergence the vertices of the closest face can tie to the last bit.  The oracle's scan keeps the
     first maximum (lowest id); a climb that only moves to strictly better neighbours ended wherever it had started, so a finer
-    direction map changed link 3 of this Obs state by 1.5e-7 m.  The record chains now list the vertex and its neighbours by
-    descending id and the device keeps `>=`, which walks ties down to the scan's vertex."""
+    direction map changed link 3 of this Obs state by 1.5e-7 m.  (Round 3: no climb any more -- a cell's candidates are listed by
+    descending id and the device keeps `>=`, so the lowest id among exactly tied values wins, like in the scan.)"""
     from ur_gym_amd import _abi
 
     n = 2048

@@ -620,6 +620,53 @@ def test_auto_reset_paths_match_oracle(oracle, monkeypatch, prefetch):
     env.close()
 
 
+def test_invalidate_records_after_episode_id_edits(oracle):
+    """urgym_invalidate_records (what set_state calls when episode_id / step_count are edited) must really invalidate.  Two edits that
+    defeat a mere "fallback window": (1) episode_id + 1 -- the slot of parity (e + 1) still holds a record keyed e + 1, so the first
+    finish would be consumed inline with no fallback while the other slot holds key e where e + 2 is needed, up to 2 x max_episode_steps
+    later; (2) the state rewound by one step right after terminal steps (episode ids go back), replaying them -- the consumed slots' keys
+    match the rewound ids again while their refill is pending.  Both followed by more than 2 x max_episode_steps steps against the oracle:
+    every output every step, no STALE_RECORD, same status words."""
+    kind, n, tmax = _abi.ENV_DYN, 384, 12
+    env = make_vec("UR5DynReach-v1", num_envs=n, seed=71, max_episode_steps=tmax)
+    orc = oracle.OracleEnv(kind, n, threads=8, max_episode_steps=tmax)
+    env.reset(seed=71)
+    orc.reset(seed=71)
+    rng = np.random.default_rng(71)
+
+    def run(k, tag):
+        fin = 0
+        for t in range(k):
+            a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+            fin += step_both(oracle, kind, env, orc, a, where=f"{tag} step {t}")[0]
+        return fin
+
+    assert run(tmax + 3, "warm-up") > n  # every env has been through an inline reset: records in steady state
+    # (1) every episode id moves on by one
+    st = env.get_state()
+    env.set_state({"episode_id": st["episode_id"] + 1})
+    orc.buf["episode_id"][...] = orc.buf["episode_id"] + 1
+    assert run(2 * tmax + 5, "after episode_id + 1") > 2 * n
+    # (2) rewind by one step right after a step in which envs finished (their inline resets consumed record slots), and replay it
+    snap = {k: v.copy() for k, v in env.get_state().items()}
+    snap_obs = np_(env.buf["observation"]).copy()
+    osnap = {k: orc.buf[k].copy() for k in STATE}
+    osnap_obs = orc.buf["observation"].copy()
+    a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+    finished, _ = step_both(oracle, kind, env, orc, a, where="the step that is replayed")
+    assert finished > 0
+    env.set_state(snap)
+    env.buf["observation"].copy_(torch.from_numpy(snap_obs).cuda())  # (carries the stale velocity slot of the Dyn observation)
+    orc.load_state(osnap)
+    orc.buf["observation"][...] = osnap_obs
+    assert step_both(oracle, kind, env, orc, a, where="the replayed step")[0] == finished
+    assert run(2 * tmax + 5, "after the rewind") > 2 * n
+    status = np_(env.buf["status"])
+    assert not (status & _abi.STATUS_STALE_RECORD).any()
+    assert np.array_equal(status, orc.buf["status"])
+    env.close()
+
+
 def test_prefetched_reset_is_bitwise_the_reset_kernel_at_scale(monkeypatch):
     """65536 Dyn envs, 130 steps (past the step where every surviving env is truncated at once): the inline reset from
     prefetched records must leave exactly the bits the RESET kernel leaves — outputs and state, every step."""
@@ -687,11 +734,11 @@ def test_one_step_reproduces_the_reference_observation_on_the_gpu(oracle, name):
         pose = o[refpins.SLOTS[name]["obstacle"]]
         ld_state = oracle.query(o[6:12], np.r_[pose[:3], refpins.bullet_quat(pose[3:])], scope=scope)[0]
     env.set_state(refpins.state_before(name, before, ld_state))
-    if name == "dyn":  # rows 6..8 of obst_vel (the per-step displacement) are derived state: let the device derive them
-        env._refresh(None)
+    if name == "dyn":  # the twist went in as rows 0..5 of obst_vel; set_state had the device derive rows 6..8 (the per-step displacement)
         torch.cuda.synchronize()
-        assert np.abs(env.get_state()["obst_vel"][:6, 0] - before[refpins.SLOTS["dyn"]["velocity"]].astype(np.float64)).max() < 1e-12
-        env.set_state({"step_count": np.array([5], np.int32)})
+        vel = env.get_state()["obst_vel"][:, 0]
+        assert np.abs(vel[:6] - before[refpins.SLOTS["dyn"]["velocity"]].astype(np.float64)).max() == 0.0
+        assert np.abs(vel[6:] - 0.04 * vel[:3]).max() < 2e-3 and np.abs(vel[6:]).max() > 0.0  # ~ v dt, minus the drift of the 20 sub-steps
     env.step(torch.from_numpy(refpins.action_between(before, after)).cuda())
     torch.cuda.synchronize()
     dev = refpins.compare_after(name, np_(env.buf["observation"])[0], after)

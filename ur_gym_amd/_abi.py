@@ -1,7 +1,7 @@
 """ctypes mirror of include/urgym.h (struct layouts and constants only; no library is loaded here)."""
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 ENV_ORI, ENV_OBS, ENV_DYN, ENV_STA = 0, 1, 2, 3
 ENV_IDS = {"UR5OriReach-v1": ENV_ORI, "UR5ObsReach-v1": ENV_OBS, "UR5DynReach-v1": ENV_DYN, "UR5StaReach-v1": ENV_STA}
@@ -103,6 +103,7 @@ EXPORTED_SYMBOLS = [
     "urgym_rollout",
     "urgym_refresh",
     "urgym_invalidate_records",
+    "urgym_derive_obstacle_motion",
     "urgym_probe_closest",
     "urgym_probe_pose_distance",
     "urgym_enable_timing",

@@ -60,6 +60,7 @@ def lib():
     L.urgym_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.urgym_refresh.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.urgym_invalidate_records.argtypes = [C.c_void_p]
+    L.urgym_derive_obstacle_motion.argtypes = [C.c_void_p, C.c_void_p]
     L.urgym_probe_closest.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6 + [C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
     L.urgym_probe_pose_distance.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.urgym_enable_timing.argtypes = [C.c_void_p, C.c_int]

@@ -2,8 +2,8 @@
 //
 // Numeric plan: the reference evaluates this path in float64 (pybullet's double build, numpy,
 // scipy) and casts to float32 only at the observation boundary, so the device does the same: FK chain, Euler /
-// quaternion conversions, pose distances, the GJK simplex AND the hull support search are float64.  The support
-// search stays cheap because it walks the hull's surface graph instead of scanning every vertex.
+// quaternion conversions, pose distances, the GJK simplex AND the hull support function are float64.  The support
+// function stays cheap because an exact support map (candidate vertices per direction cell) replaces the scan over every vertex.
 #pragma once
 #include <stdint.h>
 #if defined(URGYM_HOST_HARNESS)
@@ -26,7 +26,7 @@ using std::fma; using std::sqrt; using std::fabs; using std::fmin; using std::fm
 // wherever it went.  Nothing of it is compiled into the product.
 #if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
 constexpr int PROF_SECTIONS = 10, PROF_COUNTERS = 20, PROF_WORDS = 1 + PROF_SECTIONS + PROF_COUNTERS;
-// counters: 0 loop trip (lanes = busy lanes), 1 record round of the hull climb, 2 chained record of a round, 3 segment case,
+// counters: 0 loop trip (lanes = busy lanes), 1 first candidate record of a hull support call, 2 chained record, 3 segment case,
 // 4 plane tests of the tetrahedron, 5 one face evaluation (triangle routine), 6..12 exits of the triangle routine (vertex A, B, edge
 // AB, vertex C, edge AC, edge BC, face interior), 13 vertex reduction, 14 draw + set-up, 15 result handling of a finished query,
 // 16 cylinder support, 17 box support, 18 early exits of the iteration (separating axis / duplicate / no progress)
@@ -238,42 +238,42 @@ struct ShapeDesc {
   double hx, hy, hz;  // core half dims (cylinder: hx = core radius, hz = core half height)
 };
 
-// Convex-hull tables in global memory (L2-resident, ~2 MB, shared by every workgroup).
-// The surface graph of each hull (Qhull triangulation, data/ur5e_model.h) is stored as RECORD CHAINS: record i (i = global
-// vertex id) holds the ids AND the exact float64 coordinates of eight entries -- vertex i itself and its neighbours, by
-// descending id -- so one hill-climbing step is a single round trip of wide, independent loads (224 contiguous bytes) instead
-// of the dependent chain offset -> ids -> coordinates.  Vertices with more than 7 neighbours chain further records through
-// `next`; unused slots of the last record repeat the lowest id (urgym_tables_host.h).
+// Convex-hull support tables in global memory (L2-resident, shared by every workgroup): an EXACT support map, no search.
+// The support vertex of a convex polytope is piecewise constant in the direction: vertex p answers exactly the directions of its
+// normal cone {d : d.p >= d.n for every neighbour n}, and the cones tile the sphere.  The directions are binned in a cube map
+// (6 faces x DIRMAP_G x DIRMAP_G cells per hull); for every cell the host lists the CANDIDATES -- all vertices whose (slightly
+// relaxed) cone meets the (slightly inflated) cell, found by clipping the cell's square against the cone's half-planes in the
+// gnomonic plane of the face (urgym_tables_host.h).  The arg-max over a cell's candidates is therefore the arg-max over the whole
+// hull, for every direction that maps to the cell -- the vertex the oracle's linear scan returns.  80 % of the cells have one
+// candidate, 98.4 % at most two, 99.95 % at most four (one 128-byte record = one cache line); the few cells around the normal of
+// a flat face shared by many vertices chain further records.  One support call = the cell's 2-byte code, then ONE record: two
+// dependent memory round trips and four candidate evaluations, whatever the hull's size.
+// (Rounds 1-2 climbed the hull's surface graph from a per-cell start vertex: 224-byte records of a vertex and seven neighbours,
+//  chained for higher degrees, a round per climbing step and a last fetch of the winner's coordinates.  Measured per wave-wide GJK
+//  iteration: 1.94 record rounds + 1.93 chained records at 23 / 4 active lanes -- 40 % of the iteration's time, a third of its vector
+//  instructions, profiles/r3/lane_table_before.txt.)
 struct alignas(16) D2 {
   double a, b;
 };
-struct alignas(16) U8 {
-  unsigned short v[8];
-};
-struct alignas(16) NbrRec {
-  int next;  // next record of the same vertex, -1 = none
+struct alignas(128) CandRec {
+  int next;        // next record of the same cell list, -1 = none
   int pad[3];
-  U8 id;           // entry ids (global vertex ids)
-  D2 x[4], y[4], z[4];  // entry j: (x[j/2], y[j/2], z[j/2]).{a|b}
+  D2 x[2], y[2], z[2];  // candidate j: (x[j/2], y[j/2], z[j/2]).{a|b}, by DESCENDING vertex id; unused slots repeat the last one
 };
-static_assert(sizeof(NbrRec) == 224, "record layout");
-// Direction map: for each hull a cube map (6 faces x DIRMAP_G x DIRMAP_G cells) of the support vertex of the cell's centre
-// direction.  The hill climb STARTS there, usually AT the answer, instead of walking across the hull from a seed or from the
-// previous iteration's vertex: with those starts 6 % of the searches needed 15 or more records, so practically every wave-wide
-// iteration paid for such a walk.  A wave pays the maximum over its lanes: 2.3 rounds per search with 32 x 32 cells, 2.0 with
-// 128 x 128 (1.06 on average; 1.2 MB for the six hulls, L2-resident): +9 % env-steps/s.  The map only picks the start -- the
-// answer is still the exact float64 arg-max the climb ends at.
+static_assert(sizeof(CandRec) == 128, "record layout");
 #ifndef URGYM_DIRMAP_G
 #define URGYM_DIRMAP_G 128
 #endif
 constexpr int DIRMAP_G = URGYM_DIRMAP_G;
 constexpr int DIRMAP_CELLS = 6 * DIRMAP_G * DIRMAP_G;  // per hull
-struct HullGraph {
-  const double* __restrict__ verts;           // [NV][3] exact link-frame vertices
-  const NbrRec* __restrict__ recs;            // [NV + overflow]
-  const unsigned short* __restrict__ dirmap;  // [6 hulls][6 faces][DIRMAP_G][DIRMAP_G] global vertex ids
+struct HullMap {
+  const CandRec* __restrict__ recs;           // candidate records, shared by the cells with the same candidate set
+  const unsigned short* __restrict__ cell;    // [6 hulls][6 faces][DIRMAP_G][DIRMAP_G] -> first record of the cell's list
 };
-__device__ __forceinline__ int dirmap_cell(D3 d) {  // float32 is plenty: any cell is a valid start
+// cell of a direction.  float32 on purpose: the host builds every cell's list for the cell inflated by far more than this
+// arithmetic can err (margin 1e-5 of the face's [-1, 1] square against ~1e-7), so a direction that lands in a neighbouring cell
+// by rounding still finds its support vertex listed there.
+__device__ __forceinline__ int dirmap_cell(D3 d) {
   const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
   const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
   const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
@@ -285,7 +285,7 @@ __device__ __forceinline__ int dirmap_cell(D3 d) {  // float32 is plenty: any ce
 #ifdef URGYM_HOST_HARNESS
   const float inv = 1.0f / am;
 #else
-  const float inv = __builtin_amdgcn_rcpf(am);  // 1 ulp is plenty: the cell only picks where the exact climb starts
+  const float inv = __builtin_amdgcn_rcpf(am);  // (1 ulp: covered by the inflation of the cells)
 #endif
   int iu = (int)((u * inv + 1.0f) * (0.5f * DIRMAP_G));
   int iv = (int)((v * inv + 1.0f) * (0.5f * DIRMAP_G));
@@ -307,63 +307,44 @@ __device__ __forceinline__ double vdot3(double x, double y, double z, D3 d) {
 }
 #endif
 
-// branch-free "keep the better candidate" (selects only: the loads above it can all be in flight together).  Only the
-// value and the id are tracked; the winner's coordinates are fetched once, when the climb has ended.
-// ">=": a record chain lists the vertex itself and its neighbours by DESCENDING id (urgym_tables_host.h), so among exactly tied
+// branch-free "keep the better candidate".  ">=": a cell's candidates are listed by DESCENDING vertex id, so among exactly tied
 // values the LOWEST id is the one kept -- the vertex the oracle's scan (first maximum) returns.  Near convergence the vertices of
-// the closest face tie to the last bit now and then; without this rule the answer would depend on where the climb started.  (The
-// maximisers of a linear function on a convex polytope form a face, whose vertices are connected: walking ties downwards in id
-// ends at the scan's vertex.)
-__device__ __forceinline__ void keep_better(double x, double y, double z, int id, D3 d, double& best, int& nxt) {
+// the closest face tie to the last bit now and then (11 of 292 000 support calls of a random census).
+__device__ __forceinline__ void keep_better(double x, double y, double z, D3 d, double& best, D3& p) {
   const double t = vdot3(x, y, z, d);
   const bool g = t >= best;
   best = g ? t : best;
-  nxt = g ? id : nxt;
-}
-// four candidates packed as two D2 triples + their ids: the six 16-byte coordinate loads are issued before the first use
-// (eight at once would need 48 VGPRs for the coordinates alone and costs a wave per SIMD)
-__device__ __forceinline__ void keep_best_of4(int i0, int i1, int i2, int i3, const D2* xp, const D2* yp, const D2* zp, D3 d,
-                                             double& best, int& nxt) {
-  const D2 x0 = xp[0], x1 = xp[1];
-  const D2 y0 = yp[0], y1 = yp[1];
-  const D2 z0 = zp[0], z1 = zp[1];
-  keep_better(x0.a, y0.a, z0.a, i0, d, best, nxt);
-  keep_better(x0.b, y0.b, z0.b, i1, d, best, nxt);
-  keep_better(x1.a, y1.a, z1.a, i2, d, best, nxt);
-  keep_better(x1.b, y1.b, z1.b, i3, d, best, nxt);
+  p.x = g ? x : p.x; p.y = g ? y : p.y; p.z = g ? z : p.z;
 }
 
-// Support vertex of hull `h` in direction d by steepest-ascent hill climbing on the hull's surface graph, in float64.
-// On a convex polytope a vertex with no better neighbour is a global maximiser of the linear function, so this is
-// the exact arg-max (tools/gen_model.py re-checks that against brute force when it builds the graph).  The start comes
-// from the direction map; one climbing step = one round trip: the whole 224-byte record of the current vertex at once
-// (the vertex itself is one of its entries, so a round ranks it together with its neighbours).
-__device__ __forceinline__ D3 hull_support_climb(const HullGraph& g, int h, D3 d URGYM_PROF_PARAM) {
-  int cur = g.dirmap[h * DIRMAP_CELLS + dirmap_cell(d)];
-  for (;;) {
-    int nxt = cur;
-    int rec = cur;
-    double best = -1.0e300;
-    URGYM_LANE_MARK_AT(clk, 1);
-    do {
-      if (rec != cur) URGYM_LANE_MARK_AT(clk, 2);
-      const NbrRec& R = g.recs[rec];
-      const int nextrec = R.next;
-      const U8 id = R.id;  // header + ids travel with the first half's coordinates
-      keep_best_of4(id.v[0], id.v[1], id.v[2], id.v[3], &R.x[0], &R.y[0], &R.z[0], d, best, nxt);
-      keep_best_of4(id.v[4], id.v[5], id.v[6], id.v[7], &R.x[2], &R.y[2], &R.z[2], d, best, nxt);
-      rec = nextrec;
-    } while (rec >= 0);
-    if (nxt == cur) break;
-    cur = nxt;
-  }
-  const double* p = g.verts + 3 * cur;  // one more load for the winner's coordinates
-  return d3(p[0], p[1], p[2]);
+// Support vertex of hull `h` in direction d (link frame): the exact float64 arg-max over the candidates of d's cell.
+__device__ __forceinline__ D3 hull_support(const HullMap& g, int h, D3 d URGYM_PROF_PARAM) {
+  int rec = g.cell[h * DIRMAP_CELLS + dirmap_cell(d)];
+  double best = -1.0e300;
+  D3 p = d3(0.0, 0.0, 0.0);
+#if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+  bool first = true;
+#endif
+  do {
+#if defined(URGYM_STAMPS) && !defined(URGYM_HOST_HARNESS)
+    URGYM_LANE_MARK_AT(clk, first ? 1 : 2);
+    first = false;
+#endif
+    const CandRec& R = g.recs[rec];
+    const int nextrec = R.next;
+    const D2 x0 = R.x[0], x1 = R.x[1], y0 = R.y[0], y1 = R.y[1], z0 = R.z[0], z1 = R.z[1];  // the six 16-byte loads issue together
+    keep_better(x0.a, y0.a, z0.a, d, best, p);
+    keep_better(x0.b, y0.b, z0.b, d, best, p);
+    keep_better(x1.a, y1.a, z1.a, d, best, p);
+    keep_better(x1.b, y1.b, z1.b, d, best, p);
+    rec = nextrec;
+  } while (rec >= 0);
+  return p;
 }
 
-__device__ __forceinline__ D3 support_local(const HullGraph& g, const ShapeDesc& s, D3 d URGYM_PROF_PARAM) {
+__device__ __forceinline__ D3 support_local(const HullMap& g, const ShapeDesc& s, D3 d URGYM_PROF_PARAM) {
   if (s.type == SH_HULL) {
-    return hull_support_climb(g, s.hull, d URGYM_PROF_PASS(clk));
+    return hull_support(g, s.hull, d URGYM_PROF_PASS(clk));
   } else if (s.type == SH_CYLZ) {
     URGYM_LANE_MARK_AT(clk, 16);
     double sn = sqrt(d.x * d.x + d.y * d.y);
@@ -473,7 +454,7 @@ __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int de
 // the origin, i.e. an UPPER bound of the core distance: once it is <= verdict_d the answer is yes whatever the search would still
 // find, and the search stops there (Bullet converges first and compares then -- same verdict).  The matching lower bound is the
 // early-out above: such a caller hands in max_d = verdict_d.
-__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d,
+__device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d,
                                             double verdict_d = 0.0) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
@@ -665,7 +646,7 @@ __device__ __forceinline__ bool epa_plane(D3 pi, D3 pj, D3 pk, D3& n, double& d)
   return false;
 }
 // T: pose of A in B's frame, stored at M[0..11][0] of `ws` (XRef{ws.base, ws.stride}).  Returns depth(cores) >= 0.
-__device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const ShapeDesc& B, EpaWs ws, int lane, bool& capped) {
+__device__ inline double epa_wave(const HullMap& g, const ShapeDesc& A, const ShapeDesc& B, EpaWs ws, int lane, bool& capped) {
   const XRef T{ws.base, ws.stride};
   auto supp = [&](D3 n) -> D3 { return apply(T, support_local(g, A, rotT(T, n) URGYM_PROF_PASS(nullptr))) - support_local(g, B, -n URGYM_PROF_PASS(nullptr)); };
   const double t = 0.5773502691896258;
@@ -807,7 +788,7 @@ __device__ inline double epa_wave(const HullGraph& g, const ShapeDesc& A, const 
 #endif  // !URGYM_HOST_HARNESS
 
 // convenience wrapper: run one query to the end
-__device__ __forceinline__ double gjk_core_distance(const HullGraph& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
+__device__ __forceinline__ double gjk_core_distance(const HullMap& g, const ShapeDesc& A, XRef T, const ShapeDesc& B,
                                                     D3 v0, double max_d, int& info, double verdict_d = 0.0) {
   GjkRun r;
   gjk_begin(r, v0);

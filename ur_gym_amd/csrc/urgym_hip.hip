@@ -110,7 +110,7 @@ enum { REC_GOAL = 0, REC_START = 6, REC_END = 12, REC_VEL = 18, REC_QUAT = 24, R
 struct KParams {
   urgym_config cfg;
   urgym_buffers buf;
-  HullGraph graph;  // convex-hull vertex / adjacency / seed tables (device global memory)
+  HullMap graph;    // exact support map of the six link hulls (device global memory; urgym_device.h)
   int obs_dim, goal_dim;
   uint32_t seed_lo, seed_hi;
   int pp;           // which done_count slot this launch appends to (STEP) / consumes (RESET)
@@ -1458,7 +1458,7 @@ __global__ void ee_pose_kernel(const double* q, float* out) {
 }
 
 // unit probe: one closest-distance query per lane through the very same device GJK (tests only; not on the hot path)
-__global__ void probe_closest_kernel(HullGraph g, int count, const int* type_a, const double* par_a, const double* pose_a,
+__global__ void probe_closest_kernel(HullMap g, int count, const int* type_a, const double* par_a, const double* pose_a,
                                      const int* type_b, const double* par_b, const double* pose_b, double threshold,
                                      double* out_dist, int* out_info) {
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1533,6 +1533,17 @@ __global__ void probe_pose_distance_kernel(int count, const double* a6, const do
   out2[2 * i + 1] = angular_distance(a + 3, b + 3);
 }
 
+// rows 6..8 of obst_vel (displacement of one env step) re-derived from the twist in rows 0..5, for every env: what reset / refresh
+// do after they have computed the twist, for a caller that wrote a twist of its own (urgym_derive_obstacle_motion)
+__global__ void derive_displacement_kernel(double* obst_vel, int N, double dt) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  double vel[6], dp[3];
+  for (int i = 0; i < 6; i++) vel[i] = obst_vel[(size_t)i * N + n];
+  step_displacement(vel, dt, dp);
+  for (int i = 0; i < 3; i++) obst_vel[(size_t)(6 + i) * N + n] = dp[i];
+}
+
 // compaction of an explicit reset / refresh mask into done_list (mask == nullptr: every env)
 __global__ void build_list_kernel(const uint8_t* mask, int N, int* list, int* count) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1556,9 +1567,8 @@ struct Handle {
   double* d_ld_scratch = nullptr;  // [5][N] link distances of the running step
   double* d_sc_scratch = nullptr;  // [SC_FIELDS][N] set-up cache of the running step
   bool sc_frames = false;          // ... with the link frames (URGYM_SETUP_CACHE=2; default 1: without them; 0: no cache at all)
-  double* d_verts64 = nullptr;
-  NbrRec* d_recs = nullptr;
-  unsigned short* d_dirmap = nullptr;
+  CandRec* d_recs = nullptr;          // support map: candidate records ...
+  unsigned short* d_cell = nullptr;   // ... and the cube map of directions that points into them
   uint64_t seed = 0;
   int pp = 0;
   int step_envs = GROUP;  // envs per workgroup of the step kernel (see urgym_create)
@@ -1658,9 +1668,8 @@ KParams make_params(Handle* h, int copy_final) {
   KParams P;
   P.cfg = h->cfg;
   P.buf = h->buf;
-  P.graph.verts = h->d_verts64;
   P.graph.recs = h->d_recs;
-  P.graph.dirmap = h->d_dirmap;
+  P.graph.cell = h->d_cell;
   P.obs_dim = h->obs_dim;
   P.goal_dim = h->goal_dim;
   P.seed_lo = (uint32_t)h->seed;
@@ -1919,6 +1928,7 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   memcpy(t.joint_xyz, UR5E_JOINT_XYZ, sizeof(t.joint_xyz));
   memcpy(t.capsule, UR5E_CAPSULE, sizeof(t.capsule));
   const HostTables& tabs = build_host_tables();
+  if (!tabs.ok) { delete h; return fail(nullptr, URGYM_ERR_STATE, "urgym_create: support map has more records than a 16-bit cell code addresses"); }
   e = hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t));
   if (e != hipSuccess) { delete h; return fail(nullptr, URGYM_ERR_HIP, "hipMemcpyToSymbol(c_tab)", e); }
   auto upload = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
@@ -1934,15 +1944,13 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
   h->sc_frames = sc_level >= 2;
   if (e == hipSuccess && sc_level != 0)
     e = hipMalloc((void**)&h->d_sc_scratch, sizeof(double) * (h->sc_frames ? SC_FIELDS : SC_FRAMES) * (size_t)cfg->num_envs);
-  if (e == hipSuccess) e = upload((void**)&h->d_verts64, UR5E_HULL_VERTS, sizeof(UR5E_HULL_VERTS));
-  if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(NbrRec));
-  if (e == hipSuccess) e = upload((void**)&h->d_dirmap, tabs.dirmap.data(), tabs.dirmap.size() * sizeof(unsigned short));
+  if (e == hipSuccess) e = upload((void**)&h->d_recs, tabs.recs.data(), tabs.recs.size() * sizeof(CandRec));
+  if (e == hipSuccess) e = upload((void**)&h->d_cell, tabs.cell.data(), tabs.cell.size() * sizeof(unsigned short));
   if (e != hipSuccess) {
     if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
     if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-    if (h->d_verts64) hipFree(h->d_verts64);
     if (h->d_recs) hipFree(h->d_recs);
-    if (h->d_dirmap) hipFree(h->d_dirmap);
+    if (h->d_cell) hipFree(h->d_cell);
     delete h;
     return fail(nullptr, URGYM_ERR_HIP, "hull table upload", e);
   }
@@ -2048,9 +2056,8 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
         release_prefetch(h);
         if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
         if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-            if (h->d_verts64) hipFree(h->d_verts64);
         if (h->d_recs) hipFree(h->d_recs);
-        if (h->d_dirmap) hipFree(h->d_dirmap);
+        if (h->d_cell) hipFree(h->d_cell);
         delete h;
         return fail(nullptr, URGYM_ERR_HIP, "prefetch buffers", pe);
       }
@@ -2072,9 +2079,8 @@ int urgym_destroy(void* handle) {
   for (auto e : h->ev) hipEventDestroy(e);
   if (h->d_ld_scratch) hipFree(h->d_ld_scratch);
   if (h->d_sc_scratch) hipFree(h->d_sc_scratch);
-  if (h->d_verts64) hipFree(h->d_verts64);
   if (h->d_recs) hipFree(h->d_recs);
-  if (h->d_dirmap) hipFree(h->d_dirmap);
+  if (h->d_cell) hipFree(h->d_cell);
   delete h;
   return URGYM_OK;
 }
@@ -2113,7 +2119,31 @@ int urgym_reset(void* handle, const uint8_t* mask_dev, uint64_t seed, void* stre
 int urgym_invalidate_records(void* handle) {
   Handle* h = (Handle*)handle;
   if (!h) return fail(nullptr, URGYM_ERR_ARG, "null handle");
+  if (h->prefetch) {
+    // Really invalidate (like urgym_bind): wipe every record key and every pending refill entry, so that EVERY env takes the
+    // kernel fallback at its first finish and comes out of it with fresh records for its next two episodes -- which is what makes the
+    // max_episode_steps + 1 window sufficient.  Merely opening the window is not: after an episode_id edit one of an env's two slots
+    // can still carry a key that matches again later (the env would then be reset inline from it once the window has closed while
+    // its other slot is stale), and a refill entry filed before the edit could rewrite a slot the step is reading.
+    // The caller has just edited the bound buffers from the host side, i.e. between launches: wait for whatever is in flight.
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemset(h->d_reci, 0xFF, sizeof(int32_t) * 4 * (size_t)h->cfg.num_envs));
+    HIP_TRY(h, hipMemset(h->d_rcount, 0, sizeof(int) * 5));
+  }
   h->dirty_steps = h->cfg.max_episode_steps + 1;
+  return URGYM_OK;
+}
+
+int urgym_derive_obstacle_motion(void* handle, void* stream) {
+  Handle* h = (Handle*)handle;
+  int rc = check_bound(h);
+  if (rc) return rc;
+  if (h->cfg.env_kind == URGYM_ENV_ORI) return URGYM_OK;  // no obstacle
+  HIP_TRY(h, hipSetDevice(h->device));
+  const int N = h->cfg.num_envs;
+  hipLaunchKernelGGL(derive_displacement_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->buf.obst_vel, N, h->cfg.dt);
+  HIP_TRY(h, hipGetLastError());
   return URGYM_OK;
 }
 
@@ -2153,8 +2183,8 @@ int urgym_probe_closest(void* handle, int count, const int* type_a, const double
   if (!h || count < 0) return fail(h, URGYM_ERR_ARG, "urgym_probe_closest: bad argument");
   HIP_TRY(h, hipSetDevice(h->device));
   if (count == 0) return URGYM_OK;
-  HullGraph g;
-  g.verts = h->d_verts64; g.recs = h->d_recs; g.dirmap = h->d_dirmap;
+  HullMap g;
+  g.recs = h->d_recs; g.cell = h->d_cell;
   hipLaunchKernelGGL(probe_closest_kernel, dim3((count + 63) / 64), dim3(64), 0, (hipStream_t)stream, g, count, type_a, par_a, pose_a,
                      type_b, par_b, pose_b, threshold, out_dist, out_info);
   HIP_TRY(h, hipGetLastError());

@@ -248,10 +248,20 @@ class UR5ReachVectorEnv:
 
     def set_state(self, state, refresh=False):
         """Overwrite state tensors (teacher-forced parity tests). With refresh=True the observation, collision flag and
-        link distances are recomputed for all envs (obstacle placed at obst_start)."""
+        link distances are recomputed for all envs (obstacle placed at obst_start).  `obst_vel` may be given as the full [9, N]
+        snapshot of get_state() or as a [6, N] twist, in which case the per-step displacement (rows 6..8) is re-derived from it."""
+        derive = False
         for k, v in state.items():
-            t = torch.as_tensor(np.asarray(v), device=self.device).reshape(self.buf[k].shape)
+            v = np.asarray(v)
+            if k == "obst_vel" and v.shape[0] == 6:
+                # a twist of the caller's own (rows 0..5): rows 6..8, the displacement of one env step under it, are derived state
+                self.buf[k][:6].copy_(torch.as_tensor(v, device=self.device).reshape(6, self.num_envs).to(self.buf[k].dtype))
+                derive = True
+                continue
+            t = torch.as_tensor(v, device=self.device).reshape(self.buf[k].shape)
             self.buf[k].copy_(t.to(self.buf[k].dtype))
+        if derive:
+            _native.check(self.lib.urgym_derive_obstacle_motion(self._h, self._stream()), self._h)
         if "episode_id" in state or "step_count" in state:
             # the library keeps the next episodes of every env prefetched, keyed by episode id: tell it they may no longer match
             _native.check(self.lib.urgym_invalidate_records(self._h), self._h)
