@@ -641,12 +641,12 @@ def test_invalidate_records_after_episode_id_edits(oracle):
             fin += step_both(oracle, kind, env, orc, a, where=f"{tag} step {t}")[0]
         return fin
 
-    assert run(tmax + 3, "warm-up") > n  # every env has been through an inline reset: records in steady state
+    assert run(tmax + 3, "warm-up") >= n  # every env has been through an inline reset: records in steady state
     # (1) every episode id moves on by one
     st = env.get_state()
     env.set_state({"episode_id": st["episode_id"] + 1})
     orc.buf["episode_id"][...] = orc.buf["episode_id"] + 1
-    assert run(2 * tmax + 5, "after episode_id + 1") > 2 * n
+    assert run(2 * tmax + 5, "after episode_id + 1") >= 2 * n
     # (2) rewind by one step right after a step in which envs finished (their inline resets consumed record slots), and replay it
     snap = {k: v.copy() for k, v in env.get_state().items()}
     snap_obs = np_(env.buf["observation"]).copy()
@@ -660,7 +660,7 @@ def test_invalidate_records_after_episode_id_edits(oracle):
     orc.load_state(osnap)
     orc.buf["observation"][...] = osnap_obs
     assert step_both(oracle, kind, env, orc, a, where="the replayed step")[0] == finished
-    assert run(2 * tmax + 5, "after the rewind") > 2 * n
+    assert run(2 * tmax + 5, "after the rewind") >= 2 * n
     status = np_(env.buf["status"])
     assert not (status & _abi.STATUS_STALE_RECORD).any()
     assert np.array_equal(status, orc.buf["status"])

@@ -80,7 +80,7 @@ if not args.reset_kernel:
     for i in (1, 2, 6, 7, 3, 4, 5):
         print(f"    {names[i]:52s} {us(sect[:, :, i].sum()) / trips.sum():6.2f}   {100 * sect[:, :, i].sum() / tot:5.1f} %")
     # lane counters: (executions by the wave, active lanes summed over them)
-    cn = ("loop trip (lanes = busy lanes)", "hull climb: record round", "hull climb: chained record", "simplex: segment case",
+    cn = ("loop trip (lanes = busy lanes)", "hull support: first candidate record", "hull support: chained record", "simplex: segment case",
           "simplex: four plane tests (tetrahedron)", "simplex: one face evaluation", "  triangle exit: vertex A", "  triangle exit: vertex B",
           "  triangle exit: edge AB (division)", "  triangle exit: vertex C", "  triangle exit: edge AC (division)", "  triangle exit: edge BC (division)",
           "  triangle exit: face interior (division)", "vertex reduction", "draw + set-up", "result handling of a finished query",
@@ -88,7 +88,7 @@ if not args.reset_kernel:
     cnt = st[:, :, 24:44]
     ex = (cnt & 0xFFFFFFFF).astype(np.float64).sum(axis=(0, 1)); ln = (cnt >> 32).astype(np.float64).sum(axis=(0, 1))
     T = float(trips.sum())
-    busy = ln[0] / max(ex[0], 1.0)
+    busy = ln[0] / max(T, 1.0)  # (busy lanes summed over the trips / trips)
     print(f"  LANE TABLE (all waves of the last launch; a wave instruction is issued for 64 lanes whatever the exec mask holds)")
     print(f"    busy lanes per loop trip: {busy:.1f} of 64 = {100 * busy / 64:.1f} %   (idle-lane term: {100 * (1 - busy / 64):.1f} % of every issued lane is an idle lane)")
     print(f"    {'code':58s} {'executions per trip':>20s} {'active lanes per execution':>28s} {'of the busy lanes':>18s}")

@@ -954,8 +954,10 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       trips++;
 #ifdef URGYM_STAMPS
       trips_self += (__ballot(busy && kind == Q_SELF) != 0ull) ? 1 : 0;
-      if (busy) lane_mark(clk, 0);
-      else if (__ballot(busy) == 0ull && lane == 0) { URGYM_LDS unsigned int* w = (URGYM_LDS unsigned int*)(clk + 1 + PROF_SECTIONS); w[0] += 1u; }  // a trip nobody is busy in
+      {  // counter 0: one execution per trip, lanes = the busy ones
+        const unsigned long long bm = __ballot(busy);
+        if (lane == 0) { URGYM_LDS unsigned int* w = (URGYM_LDS unsigned int*)(clk + 1 + PROF_SECTIONS); w[0] += 1u; w[1] += (unsigned int)__popcll(bm); }
+      }
 #endif
       if (busy) {
         // exact queries (link distances): Bullet's early-out distance of getClosestPoints(distance = 5.0).  Boolean queries ("closer
@@ -1439,8 +1441,19 @@ __global__ void __launch_bounds__(THREADS, URGYM_RESIDENT) env_step_fused(const 
     EnvLds<MODE_STEP> step;
     EnvLds<MODE_PREFETCH> refill;
   } lds;
-  if ((int)blockIdx.x < step_blocks) env_body<KIND, MODE_STEP, WITH_EPA>(Ps, actions, lds.step, (int)blockIdx.x, step_blocks);
-  else env_body<KIND, MODE_PREFETCH, true>(Pr, nullptr, lds.refill, (int)blockIdx.x - step_blocks, (int)gridDim.x - step_blocks);
+  if ((int)blockIdx.x < step_blocks) {
+    env_body<KIND, MODE_STEP, WITH_EPA>(Ps, actions, lds.step, (int)blockIdx.x, step_blocks);
+  } else {
+    // the refill workgroups stride over the list in chunks of PREFETCH_MAX_ENVS entries: their number is a scheduling choice of the
+    // host (launch_fused), any number serves any list length
+    const int rb = (int)blockIdx.x - step_blocks, nrb = (int)gridDim.x - step_blocks;
+    const int count = min(*Pr.rcount, Pr.rcap);  // complete: the launch that appended to this list has finished
+#pragma unroll 1
+    for (int chunk = rb; chunk * PREFETCH_MAX_ENVS < count; chunk += nrb) {
+      env_body<KIND, MODE_PREFETCH, true>(Pr, nullptr, lds.refill, chunk, nrb);
+      __syncthreads();  // the next chunk re-uses the LDS slots
+    }
+  }
 }
 
 // end-effector pose of a joint vector exactly as P4 derives it (urgym_create evaluates the neutral pose once)
@@ -1599,6 +1612,15 @@ struct Handle {
   // urgym_invalidate_records / a reset that did not cover every env): only then does a step carry the fallback launches.
   // An env that falls back gets fresh records for its next two episodes, and every env finishes within max_episode_steps.
   int dirty_steps = 0;
+  int refill_blocks_override = 0;   // URGYM_REFILL_BLOCKS (tuning / tests): refill workgroups per fused launch, 0 = the policy of launch_fused
+  long steps_since_full_reset = -1; // step launches since the last urgym_reset of every env (-1: none yet)
+  // the refill of a step's finished envs rides in the NEXT launch: a burst that happens in step k * max_episode_steps (counted from 1)
+  // is served one launch later; allow a step of slack on either side
+  bool burst_due() const {
+    if (steps_since_full_reset < 0 || cfg.max_episode_steps < 4) return true;
+    const long r = steps_since_full_reset % cfg.max_episode_steps;
+    return steps_since_full_reset >= cfg.max_episode_steps - 1 && (r <= 2 || r == cfg.max_episode_steps - 1);
+  }
 };
 thread_local char g_err[512] = {0};
 
@@ -1738,7 +1760,15 @@ void launch_fused(Handle* h, KParams Ps, KParams Pr, const float* actions, hipSt
     step_blocks = h->big_blocks + (n - (long)h->big_blocks * envs + h->tail_envs - 1) / h->tail_envs;
   }
   Pr.envs = PREFETCH_MAX_ENVS;
-  const long refill_blocks = ((long)Pr.rcap + PREFETCH_MAX_ENVS - 1) / PREFETCH_MAX_ENVS;  // an upper bound: most exit at once
+  // Refill workgroups: they stride over the list, so their number only decides how parallel the refill is.  About 1.6 % of the envs
+  // finish per step under a random policy (N / 1920 chunks of 32); the grid carries four times that, at least 64 -- and the whole
+  // list's worth (one workgroup per possible chunk) in the steps where a burst is due: every env that survives from a full reset is
+  // truncated max_episode_steps later, all in the same step (and their successors again a period later).
+  const long full = ((long)Pr.rcap + PREFETCH_MAX_ENVS - 1) / PREFETCH_MAX_ENVS;
+  long refill_blocks = std::max(64L, 4 * (n / 1920 + 1));
+  if (h->refill_blocks_override > 0) refill_blocks = h->refill_blocks_override;
+  else if (h->burst_due()) refill_blocks = full;
+  if (refill_blocks > full) refill_blocks = full;
   dim3 grid((unsigned)(step_blocks + refill_blocks)), block(THREADS);
   const bool epa = !h->cfg.check_collision;  // (which STEP launches can consume a penetration depth: see need_epa in the kernel)
   const int sb = (int)step_blocks;
@@ -1845,6 +1875,7 @@ int do_step(Handle* h, const float* actions, hipStream_t s) {
     }
     h->parity = nxt;
   }
+  if (h->steps_since_full_reset >= 0) h->steps_since_full_reset++;
   h->pp ^= 1;
   HIP_TRY(h, hipGetLastError());
   return URGYM_OK;
@@ -1877,6 +1908,7 @@ int do_masked(Handle* h, const uint8_t* mask, int mode, hipStream_t s) {
       launch_mode<MODE_PREFETCH>(h, P, nullptr, 8, s, h->rl_cap[3]);  // the next two episodes of every env just reset
       if (mask == nullptr) h->dirty_steps = 0;                          // every env now has valid records
     }
+    if (mask == nullptr) h->steps_since_full_reset = 0;                 // every step counter is 0: the truncation bursts are now predictable
   } else {
     launch_mode<MODE_REFRESH>(h, P, nullptr, GROUP, s);
   }
@@ -1965,11 +1997,23 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
     int cus = 256, per_cu = 3;
     hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     hipError_t oe = hipSuccess;
+    // (of the kernel instance the steady-state step really launches: the fused STEP + PREFETCH kernel for the obstacle envs with
+    //  auto-reset, the plain STEP kernel otherwise.  The API over-reports near the LDS limit -- DESIGN.md section 4 "toolchain hazards";
+    //  the residency census, tools/diag/census.hip, is what the cap URGYM_RESIDENT = 3 below rests on.)
+    const bool fused = cfg->env_kind != URGYM_ENV_ORI && cfg->auto_reset && !(getenv("URGYM_PREFETCH") && atoi(getenv("URGYM_PREFETCH")) == 0);
+    const bool epa = !cfg->check_collision;
+    auto occ = [&](auto kernel) { return hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, THREADS, 0); };
     switch (cfg->env_kind) {
-      case URGYM_ENV_ORI: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_ORI, MODE_STEP, false>, THREADS, 0); break;
-      case URGYM_ENV_OBS: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_OBS, MODE_STEP, true>, THREADS, 0); break;
-      case URGYM_ENV_STA: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_STA, MODE_STEP, false>, THREADS, 0); break;
-      default: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, env_kernel<URGYM_ENV_DYN, MODE_STEP, false>, THREADS, 0); break;
+      case URGYM_ENV_ORI: oe = occ(env_kernel<URGYM_ENV_ORI, MODE_STEP, false>); break;
+      case URGYM_ENV_OBS: oe = fused ? occ(env_step_fused<URGYM_ENV_OBS, true>) : occ(env_kernel<URGYM_ENV_OBS, MODE_STEP, true>); break;
+      case URGYM_ENV_STA:
+        if (fused) oe = epa ? occ(env_step_fused<URGYM_ENV_STA, true>) : occ(env_step_fused<URGYM_ENV_STA, false>);
+        else oe = epa ? occ(env_kernel<URGYM_ENV_STA, MODE_STEP, true>) : occ(env_kernel<URGYM_ENV_STA, MODE_STEP, false>);
+        break;
+      default:
+        if (fused) oe = epa ? occ(env_step_fused<URGYM_ENV_DYN, true>) : occ(env_step_fused<URGYM_ENV_DYN, false>);
+        else oe = epa ? occ(env_kernel<URGYM_ENV_DYN, MODE_STEP, true>) : occ(env_kernel<URGYM_ENV_DYN, MODE_STEP, false>);
+        break;
     }
     if (oe != hipSuccess || per_cu < 1) per_cu = 3;
     if (per_cu > URGYM_RESIDENT) per_cu = URGYM_RESIDENT;
@@ -2016,6 +2060,10 @@ int urgym_create(const urgym_config* cfg, int device, void** handle) {
       } else if (atoi(ov) == 0) {  // "0": uniform workgroups
         h->step_envs = (int)envs; h->big_blocks = 0; h->tail_envs = 0;
       }
+    }
+    if (const char* ov = getenv("URGYM_REFILL_BLOCKS")) {
+      const int r = atoi(ov);
+      if (r >= 1) h->refill_blocks_override = r;
     }
     if (const char* ov = getenv("URGYM_RESET_ENVS")) {
       const int r = atoi(ov);
@@ -2102,6 +2150,7 @@ int urgym_bind(void* handle, const urgym_buffers* b) {
     h->rec_seed_valid = false;
     h->dirty_steps = h->cfg.max_episode_steps + 1;
   }
+  h->steps_since_full_reset = -1;
   h->buf = *b;
   h->bound = true;
   return URGYM_OK;
@@ -2132,6 +2181,7 @@ int urgym_invalidate_records(void* handle) {
     HIP_TRY(h, hipMemset(h->d_rcount, 0, sizeof(int) * 5));
   }
   h->dirty_steps = h->cfg.max_episode_steps + 1;
+  h->steps_since_full_reset = -1;  // step counters were edited: no longer known when many envs finish at once
   return URGYM_OK;
 }
 
