@@ -33,25 +33,42 @@ sys.path.insert(0, ROOT)
 
 ALGO_BYTES = {"UR5OriReach-v1": 230, "UR5ObsReach-v1": 290, "UR5DynReach-v1": 418, "UR5StaReach-v1": 370}  # SURVEY.md §8(d); Sta = Dyn without the velocity slots
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2", "pmc_summary.json")  # rocprofv3 --pmc passes of this same command (tools/gpu_round.sh prof)
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3", "pmc_summary.json")  # rocprofv3 passes of this same command per config (tools/r3_prof.sh)
 
 
-def profiled_counters(env_id, n):
-    """Counters of the step kernel from the committed rocprofv3 PMC summary; only valid for the configuration that was
-    profiled (Dyn, N=65536).  traffic = HBM bytes per launch (FETCH_SIZE corrected x2 as the gfx950 guide prescribes + WRITE_SIZE);
-    valu_* = the VALU-issue picture of the same launches (SQ_ACTIVE_INST_VALU in quad-cycles over the SIMD-cycles of the kernel)."""
-    if env_id != "UR5DynReach-v1" or n != 65536 or not os.path.exists(PMC_SUMMARY):
-        return None, None
+def config_label(env_id, n, no_collision=False, rollout=False):
+    """Key of a profiled configuration in profiles/r3/pmc_summary.json (tools/r3_prof.sh uses the same)."""
+    return f"{env_id} N={n}" + (" no-collision" if no_collision else "") + (" rollout" if rollout else "")
+
+
+def profiled_counters(label):
+    """Counters of the dominant kernel of a profiled configuration from the committed rocprofv3 summary (separate --pmc passes of this
+    very command line; static figures of that profile, not measured in this run).  Returns (kernel name, traffic dict, valu dict).
+    traffic: L2 <-> fabric bytes per launch.  FETCH_SIZE is reported by gfx950 at half the volume for WIDE coalesced reads, which is
+    what the guide's x2 correction is for; this kernel reads mostly 8- / 16-byte gathers, so the true read volume lies between the
+    uncorrected and the corrected figure -- both are given, `traffic` (the contract's field) carries the corrected (upper) one."""
+    if not os.path.exists(PMC_SUMMARY):
+        return None, None, None
     try:
-        k = json.load(open(PMC_SUMMARY))["env_kernel<2, 0>"]
-        traffic = float(k["hbm_read_bytes_per_launch_corrected"] + k["hbm_write_bytes_per_launch"])
-        valu = {"busy_fraction_of_simd_cycles": k.get("valu_busy_fraction_of_simd_cycles"), "lane_utilisation": k.get("valu_lane_utilisation"),
+        cfgs = json.load(open(PMC_SUMMARY))
+        kernels = cfgs.get(label)
+        if not kernels:
+            return None, None, None
+        name, k = max(kernels.items(), key=lambda kv: kv[1].get("calls", 0) * kv[1].get("avg_ns", 0.0))
+        traffic = None
+        if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+            rd, wr = k["FETCH_SIZE"] * 1024.0, k["WRITE_SIZE"] * 1024.0
+            traffic = {"corrected": 2.0 * rd + wr, "uncorrected": rd + wr, "read_uncorrected": rd, "write": wr}
+        busy, lanes = k.get("valu_busy_fraction_of_simd_cycles"), k.get("valu_lane_utilisation")
+        valu = {"busy_fraction_of_simd_cycles": busy, "lane_utilisation": lanes,
+                "valu_frac": (busy * lanes) if busy is not None and lanes is not None else None,  # useful lanes / peak lane-issue capacity
                 "wave_slot_occupancy": k.get("wave_slot_occupancy"), "wait_fraction_of_wave_cycles": k.get("wait_fraction_of_wave_cycles"),
                 "valu_wave_instructions_per_launch": k.get("SQ_INSTS_VALU"), "scratch_bytes_per_lane": k.get("Scratch_Size"),
-                "source": "profiles/r2/pmc_summary.json (static: separate rocprofv3 --pmc passes of this command, not measured in this run)"}
-        return traffic, valu
+                "vgprs_elf": k.get("vgprs_elf"), "profiled_kernel_avg_us": (k.get("avg_ns") or 0.0) / 1e3 or None,
+                "source": "profiles/r3/pmc_summary.json[%r][%r] (static: separate rocprofv3 --pmc passes of this command, not measured in this run)" % (label, name)}
+        return name, traffic, valu
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def cpu_baseline(env_id, seed, budget_s=12.0):
@@ -96,6 +113,7 @@ def cpu_baseline(env_id, seed, budget_s=12.0):
 
 STATUS_BITS = {1: "nan", 2: "reset_exhausted", 4: "reset_collision", 8: "penetration_depth_consumed", 16: "gjk_or_epa_iteration_cap",
                32: "joint_limit_passed", 64: "stale_episode_record"}
+INFORMATIONAL_BITS = 8 | 32  # include/urgym.h: a consumed penetration depth and a joint past its URDF limit are facts about the episode, not anomalies
 
 
 def parity_check(env, actions, m=512):
@@ -210,25 +228,64 @@ def main():
     gathered = None
     gloo = dist is not None and dist.get_backend() == "gloo"
     if args.gather_obs and world > 1:
-        # the optional exchange of the path: every rank ends up with all observations (RCCL all-gather over xGMI; in the
-        # one-GPU rehearsal gloo gathers through a pinned host staging buffer)
-        gathered = torch.empty((world * n, env.obs_dim), dtype=torch.float32, device="cpu" if gloo else dev)
-        stage = torch.empty((n, env.obs_dim), dtype=torch.float32, pin_memory=True) if gloo else None
+        # The optional exchange of the path: every rank ends up with all observations (RCCL all-gather over xGMI).  It OVERLAPS the
+        # next step: the step kernel starts rewriting the observation buffer at its very beginning (P1 parks the end-effector pose in
+        # the rows, every workgroup stores its rows as it finishes), so the gather must not read that buffer while the next step runs.
+        # After step t the rows are copied device-to-device into stage[t % 2] on the step's own stream (N x obs_dim x 4 B: a few
+        # microseconds), the all-gather of stage[t % 2] into gathered[t % 2] runs on a SIDE stream behind an event, and the copy of
+        # step t + 2 waits for that gather's event before it reuses the staging buffer.  A consumer reads gathered[t % 2].
+        # (one-GPU rehearsal: gloo gathers through pinned host buffers; the host part of the gather of step t runs after step t + 1
+        #  has been launched, so the same overlap is exercised)
+        side = torch.cuda.Stream(device=dev)
+        stage = [torch.empty((n, env.obs_dim), dtype=torch.float32, device=dev) for _ in range(2)]
+        gathered = [torch.empty((world * n, env.obs_dim), dtype=torch.float32, device="cpu" if gloo else dev) for _ in range(2)]
+        host = [torch.empty((n, env.obs_dim), dtype=torch.float32, pin_memory=True) for _ in range(2)] if gloo else None
+        ev_copy = [torch.cuda.Event() for _ in range(2)]
+        ev_gather = [torch.cuda.Event() for _ in range(2)]
+        pending = []          # rehearsal: (buffer index) of the gather whose host part is still to run
+        check = {"step": None, "ref": None, "ok": None}  # one sampled step: its observations, cloned, against what the gather delivered
+
+    def finish_host_gather(b):
+        ev_gather[b].synchronize()  # the device-to-host copy of stage[b]
+        dist.all_gather(list(gathered[b].view(world, n, env.obs_dim).unbind(0)), host[b])
 
     def one_step(k):
         env.step(actions[k % n_act])
         if gathered is not None:
+            b = k & 1
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(ev_gather[b])           # the gather that last read stage[b] (step k - 2) has finished
+            stage[b].copy_(env.buf["observation"])  # on the step's stream: ordered after step k, before step k + 1
+            ev_copy[b].record(main)
+            if check["step"] == k:
+                check["ref"] = env.buf["observation"].clone()
+            with torch.cuda.stream(side):
+                side.wait_event(ev_copy[b])
+                if gloo:
+                    host[b].copy_(stage[b], non_blocking=True)
+                else:
+                    dist.all_gather_into_tensor(gathered[b], stage[b])  # (c10d: the collective is ordered behind `side`, and `side` behind it)
+                ev_gather[b].record(side)
             if gloo:
-                stage.copy_(env.buf["observation"])  # (synchronises with the step on the current stream)
-                dist.all_gather(list(gathered.view(world, n, env.obs_dim).unbind(0)), stage)
-            else:
-                dist.all_gather_into_tensor(gathered, env.buf["observation"])
+                # step k is on the device; now the host part of step k - 1's gather runs beside it
+                if pending:
+                    finish_host_gather(pending.pop())
+                pending.append(b)
+            if check["step"] is not None and k == check["step"] + 1 and check["ok"] is None:
+                # step k (= sampled step + 1) has been launched; the gather of the sampled step must deliver the sampled step's rows
+                pb = check["step"] & 1
+                if not gloo:
+                    ev_gather[pb].synchronize()
+                own = gathered[pb].view(world, n, env.obs_dim)[rank]
+                check["ok"] = bool(torch.equal(own.to(dev), check["ref"]))
 
     for k in range(args.warmup):
         one_step(k)
     rollout_actions = None
     if args.rollout and gathered is None:  # resident before the timed region, like the per-step action batches
         rollout_actions = torch.stack([actions[(args.warmup + k) % n_act] for k in range(args.steps)])
+    if gathered is not None:
+        check["step"] = args.warmup + args.steps // 2
     torch.cuda.synchronize(dev)
     env.enable_timing(not args.no_kernel_timing, every=8)  # HIP events around every 8th step launch (an event pair costs the stream ~6 us)
     if dist is not None:
@@ -240,7 +297,10 @@ def main():
     else:
         for k in range(args.steps):
             one_step(args.warmup + k)
-    torch.cuda.synchronize(dev)
+    if gathered is not None and gloo:
+        while pending:
+            finish_host_gather(pending.pop())
+    torch.cuda.synchronize(dev)  # (every stream of the device: the last gather too)
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize(dev)
@@ -253,15 +313,22 @@ def main():
         elapsed = float(t.item())
 
     status = env.buf["status"]
-    anomalies = int((status != 0).sum().item())
+    anomalies = int(((status & ~INFORMATIONAL_BITS) != 0).sum().item())   # nan, reset exhausted / collision, iteration cap, stale record
+    informational = int(((status & INFORMATIONAL_BITS) != 0).sum().item())
     anomaly_bits = {name: int(((status & bit) != 0).sum().item()) for bit, name in STATUS_BITS.items()}
     episodes = int(env.buf["episode_id"].sum().item())
     if rank == 0:
         total_envs = n * world
         value = total_envs * args.steps / elapsed
         algo = ALGO_BYTES[args.env] * n  # bytes one launch of the step kernel has to move, per rank
-        traffic, valu = profiled_counters(args.env, n)
+        label = config_label(args.env, n, args.no_collision, args.rollout)
+        prof_kernel, traffic, valu = profiled_counters(label)
         achieved = algo / (step_us * 1e-6) / 1e9 if step_us > 0 else 0.0
+        fused = args.env != "UR5OriReach-v1"
+        kind_no = {"UR5OriReach-v1": 0, "UR5ObsReach-v1": 1, "UR5DynReach-v1": 2, "UR5StaReach-v1": 3}[args.env]
+        epa = (args.env == "UR5ObsReach-v1") or args.no_collision
+        kernel = (f"env_step_fused<{kind_no}, {str(epa).lower()}> (STEP workgroups + the refill of the previous step's episode records)" if fused
+                  else f"env_kernel<{kind_no}, 0, false> (STEP; finished envs reset inside the launch)")
         out = {
             "metric": "env-steps/sec (whole node)",
             "value": value,
@@ -279,24 +346,36 @@ def main():
                                    + (", collision checks OFF (FK + reward only)" if args.no_collision else ""),
                        "envs_total": total_envs, "gather_obs": bool(gathered is not None), "rollout_api": bool(args.rollout),
                        "gjk_start": args.gjk_start},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "traffic_source": "profiles/r2/pmc_summary.json (bytes per launch, separate rocprofv3 --pmc passes)",
-                         "valu_issue": valu,  # what really bounds the kernel: float64 VALU issue + the latency of the GJK chains
+            # `achieved` / `peak` / `frac` price the kernel against the HBM roofline with the algorithmic bytes of SURVEY.md section 8(d), as
+            # the measurement contract asks; `bound` names what really limits it: float64 VALU issue while the chip is full (three waves
+            # per SIMD keep the vector pipes saturated), then the latency of the longest GJK chains in the tail of the launch
+            # (DESIGN.md section 4).  valu_issue.valu_frac = VALU busy x lane utilisation = useful lanes / peak lane-issue capacity.
+            "roofline": {"bound": "valu_issue/latency", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic["corrected"] if traffic else None,
+                         "traffic_uncorrected": traffic["uncorrected"] if traffic else None,
+                         "traffic_note": "L2 <-> fabric bytes per launch, FETCH_SIZE x 1024 (x 2: the gfx950 correction for wide coalesced reads; this "
+                                         "kernel's reads are mostly 8- / 16-byte gathers, so the truth lies between the two figures) + WRITE_SIZE x 1024",
+                         "traffic_source": "profiles/r3/pmc_summary.json (separate rocprofv3 --pmc passes of this command)" if traffic else None,
+                         "valu_issue": valu,
+                         "valu_frac": valu["valu_frac"] if valu else None,
                          "algorithmic_bytes_per_launch": algo,
-                         "kernel": "env_step_fused<Dyn> (STEP workgroups + the refill of the previous step's episode records)" if args.env == "UR5DynReach-v1" else "step launch",
+                         "kernel": kernel, "profiled_kernel": prof_kernel,
                          "kernel_us": step_us, "reset_kernel_us": reset_us, "launches_timed": launches,
                          "algorithmic_bytes_per_env_step": ALGO_BYTES[args.env],
-                         "note": "bound by the dependent float64 chain of the GJK iterations (resident waves, then VALU issue), not by HBM (DESIGN.md section 4)"},
-            "anomalous_envs": anomalies,
-            "anomalous_envs_by_status_bit": anomaly_bits,  # informational bits included (include/urgym.h URGYM_STATUS_*)
+                         "note": "not HBM-bound: float64 VALU issue in the bulk of the launch, the dependent chain of the longest GJK searches in its tail (DESIGN.md section 4)"},
+            "anomalous_envs": anomalies,                       # real anomalies only
+            "informational_envs": informational,               # penetration depth consumed / joint past its URDF limit
+            "envs_by_status_bit": anomaly_bits,                # include/urgym.h URGYM_STATUS_*
             "episodes_started": episodes,
         }
         if gathered is not None:
             out["config"]["gather_bytes_per_gpu_per_step"] = n * env.obs_dim * 4
-            ok = bool(torch.equal(gathered.view(world, n, env.obs_dim)[rank].to(dev), env.buf["observation"]))
-            out["config"]["gather_own_shard_intact"] = ok
-        if not args.no_cpu_baseline and world == 1:
+            last = (args.warmup + args.steps - 1) & 1
+            out["config"]["gather_overlapped_with_next_step"] = True
+            out["config"]["gather_own_shard_intact"] = bool(torch.equal(gathered[last].view(world, n, env.obs_dim)[rank].to(dev), env.buf["observation"]))
+            out["config"]["gather_delivered_step_t_while_step_t_plus_1_ran"] = check["ok"]
+        if not args.no_cpu_baseline:  # rank 0 at any world size
             out["cpu_baseline"] = cpu_baseline(args.env, args.seed)
             out["cpu_baseline"]["parity_check"] = parity_check(env, actions[(args.warmup + args.steps) % n_act])
         print(json.dumps(out), flush=True)
