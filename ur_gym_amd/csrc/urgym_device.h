@@ -317,11 +317,8 @@ __device__ __forceinline__ void keep_better(double x, double y, double z, D3 d, 
   p.x = g ? x : p.x; p.y = g ? y : p.y; p.z = g ? z : p.z;
 }
 
-// First candidate record of hull `h` for direction d (link frame): the cell's 2-byte code.
-__device__ __forceinline__ int hull_first_record(const HullMap& g, int h, D3 d) { return g.cell[h * DIRMAP_CELLS + dirmap_cell(d)]; }
-
-// Support vertex of a hull in direction d (link frame), given the first record of d's cell: the exact float64 arg-max over the
-// cell's candidates.
+// Support vertex of a hull in direction d (link frame), given the first record of d's cell (the cell's 2-byte code): the exact
+// float64 arg-max over the cell's candidates.
 __device__ __forceinline__ D3 hull_support_from(const HullMap& g, int rec, D3 d URGYM_PROF_PARAM) {
   double best = -1.0e300;
   D3 p = d3(0.0, 0.0, 0.0);
@@ -345,7 +342,7 @@ __device__ __forceinline__ D3 hull_support_from(const HullMap& g, int rec, D3 d 
   return p;
 }
 __device__ __forceinline__ D3 hull_support(const HullMap& g, int h, D3 d URGYM_PROF_PARAM) {
-  return hull_support_from(g, hull_first_record(g, h, d), d URGYM_PROF_PASS(clk));
+  return hull_support_from(g, g.cell[h * DIRMAP_CELLS + dirmap_cell(d)], d URGYM_PROF_PASS(clk));
 }
 
 __device__ __forceinline__ D3 support_local(const HullMap& g, const ShapeDesc& s, D3 d URGYM_PROF_PARAM) {
@@ -460,19 +457,22 @@ __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int de
 // the origin, i.e. an UPPER bound of the core distance: once it is <= verdict_d the answer is yes whatever the search would still
 // find, and the search stops there (Bullet converges first and compares then -- same verdict).  The matching lower bound is the
 // early-out above: such a caller hands in max_d = verdict_d.
-// rec_a (>= 0): A is a hull and the caller has already looked up the first candidate record of this iteration's support direction
-// rotT(T, -r.v) (hull_first_record) -- the kernels issue that look-up at the END of the previous loop trip, so that its memory round
-// trip is over when the iteration starts instead of heading its dependent chain.
 __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const ShapeDesc& A, XRef T, const ShapeDesc& B, double max_d,
-                                            double verdict_d = 0.0, int rec_a = -1) {
+                                            double verdict_d = 0.0) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
   D3 w;
   {
+    // A a hull: its cell code is requested first, the support of B (for the cylinder a square root and a division: a dependent chain
+    // of its own) is evaluated while that load travels, the candidates of A's cell are fetched and ranked afterwards
     const D3 dA = rotT(T, -r.v);
-    D3 p = apply(T, rec_a >= 0 ? hull_support_from(g, rec_a, dA URGYM_PROF_PASS(r.clk)) : support_local(g, A, dA URGYM_PROF_PASS(r.clk)));
+    int rec = 0;
+    if (A.type == SH_HULL) rec = g.cell[A.hull * DIRMAP_CELLS + dirmap_cell(dA)];
+    const D3 q = support_local(g, B, r.v URGYM_PROF_PASS(r.clk));
+    URGYM_TRIP_MARK(2);
+    const D3 sA = (A.type == SH_HULL) ? hull_support_from(g, rec, dA URGYM_PROF_PASS(r.clk)) : support_local(g, A, dA URGYM_PROF_PASS(r.clk));
+    const D3 p = apply(T, sA);
     URGYM_TRIP_MARK(1);
-    D3 q = support_local(g, B, r.v URGYM_PROF_PASS(r.clk));
     w = p - q;
   }
   const double delta = dot(r.v, w);

@@ -926,26 +926,13 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     };
 
     GjkRun run;
-    gjk_begin(run, d3(0, 1, 0));  // (idle lanes look ahead too, below: defined values)
     bool busy = false;
-    // first candidate record of the hull support call of the lane's NEXT iteration, looked up at the end of every loop trip by ALL
-    // lanes on one unconditional path (idle lanes read cell 0): the load then has a single definition that reaches the next trip
-    // without a select or a merge, so its wait sits at the first use -- the top of the next iteration -- and the round trip runs under
-    // the back edge of the loop instead of heading the iteration's dependent chain
-    int next_rec = 0;
-    auto look_ahead = [&]() {
-      const D3 dn = rotT(pose_slot, -run.v);  // (idle lanes: stale slot contents, any direction will do)
-      const int h = (kind == Q_SELF ? la : lb) - 1;
-      const int cell = busy ? h * DIRMAP_CELLS + dirmap_cell(dn) : 0;
-      next_rec = P.graph.cell[cell];
-    };
     STAMP_TIME(2);
     if (MODE == MODE_STEP) p1_ok = __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
     if (tid < n_tickets) {
       busy = setup(ticket_item(tid));
       if (busy) gjk_begin(run, v0);
     }
-    look_ahead();
     STAMP_TIME(3);
     int trips = 0, draws = 0;
 #ifdef URGYM_STAMPS
@@ -978,11 +965,8 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         // stops as soon as either decides, with the verdict Bullet reaches after converging (pyb_setup.py:402-422)
         const bool wants_distance = (kind == 3 || exact);
         const double verdict_d = wants_distance ? 0.0 : margin_sum() + cfg.collision_margin;
-        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d, next_rec);
+        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d);
         SECTION(3);
-      }
-      look_ahead();  // (every lane, right after the iteration: result handling, polling and draws run while the cell code travels)
-      if (busy) {
         if (run.done) {
 #ifdef URGYM_STAMPS
           lane_mark(clk, 15);
@@ -1029,7 +1013,7 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
           lane_mark(clk, 14);
 #endif
           busy = setup(item);
-          if (busy) { gjk_begin(run, v0); look_ahead(); }
+          if (busy) gjk_begin(run, v0);
 #ifdef URGYM_STAMPS
           if (busy) run.clk = clk;
           n_boxq += __popcll(__ballot(busy && (kind == Q_TABLE || kind == Q_TRACK)));
