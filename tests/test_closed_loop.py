@@ -208,6 +208,50 @@ def test_old_checkpoints_fail_with_todays_link_dist(oracle):
         env.close()
 
 
+def test_reward_formula_of_the_2023_checkpoints(oracle):
+    """What reward produced the per-trial numbers the reference ships for its two Sep-2023 checkpoints?  One replay per env records the
+    terms of the reward per step; the trials are then priced under the code as it stands and under the 2023 hypothesis
+    (tools/reward_hypotheses.py prices a whole family: profiles/r3/reward_hypotheses.txt).
+      Obs: the code as it stands (reach.py:356-374) reproduces the distribution of the successful trials' rewards.
+      Sta: the code as it stands (reach.py:543-573: early returns, -70 d - 30 theta, link weights [8, 2.4, 1.2, 1.2, 0.2] / 13 * 50)
+           does NOT (mean -127 vs -154.7); the additive form of Ori / Obs with -70 d - 30 theta and the Obs link weight 100 does,
+           to a Kolmogorov-Smirnov distance inside the alpha = 0.001 critical value and the means within 3 standard errors."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import reward_hypotheses as rh
+
+    def compare(rew, ok, name):
+        ref, ref_ok = TRIALS[f"{name}_reward"], TRIALS[f"{name}_success"].astype(bool)
+        a, b = np.sort(rew[ok]), np.sort(ref[ref_ok])
+        grid = np.concatenate([a, b])
+        ks = float(np.abs(np.searchsorted(a, grid, side="right") / len(a) - np.searchsorted(b, grid, side="right") / len(b)).max())
+        crit = 1.95 * np.sqrt((len(a) + len(b)) / (len(a) * len(b)))
+        z = abs(rew[ok].mean() - ref[ref_ok].mean()) / se_of_difference(rew[ok].std(ddof=1), ok.sum(), ref[ref_ok].std(ddof=1), ref_ok.sum())
+        return ks, crit, z
+
+    n = 1500
+    log, ok, _ = rh.replay("obs", _abi.ENV_OBS, n, 2)
+    today = sum(np.where(s["live"], s["r_now"], 0.0) for s in log)
+    ks, crit, z = compare(today, ok, "obs")
+    assert ks < crit and z < Z, ("obs, the code as it stands", ks, crit, z)
+
+    log, ok, _ = rh.replay("sta", _abi.ENV_STA, n, 5)
+    today = sum(np.where(s["live"], s["r_now"], 0.0) for s in log)
+    ks, crit, z = compare(today, ok, "sta")
+    assert ks > crit and z > 2 * Z, ("sta, the code as it stands, should NOT reproduce the 2023 rewards", ks, crit, z)
+    # (the replayed `early / -70 d - 30 theta / Dyn weights` pricing IS the code as it stands: the tool's bookkeeping is right)
+    same = rh.price(log, n, "early", -70.0, -30.0, rh.W_DYN)
+    assert np.abs(same - today).max() < 1e-3
+    y2023 = rh.price(log, n, "additive", -70.0, -30.0, np.full(5, 100.0))
+    ks, crit, z = compare(y2023, ok, "sta")
+    assert ks < crit and z < Z, ("sta, additive form with the Obs link weight", ks, crit, z)
+    # the failed trials too (mean within 3 standard errors)
+    ref, ref_ok = TRIALS["sta_reward"], TRIALS["sta_success"].astype(bool)
+    zf = abs(y2023[~ok].mean() - ref[~ref_ok].mean()) / se_of_difference(y2023[~ok].std(ddof=1), (~ok).sum(), ref[~ref_ok].std(ddof=1), (~ref_ok).sum())
+    assert zf < Z, ("sta failed trials", y2023[~ok].mean(), ref[~ref_ok].mean(), zf)
+
+
 # ------------------------------------------------------------------------------------------------ GPU (HIP path)
 @pytest.mark.gpu
 def test_closed_loop_hip_full_protocol():

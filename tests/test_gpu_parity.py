@@ -695,6 +695,119 @@ def test_prefetched_reset_is_bitwise_the_reset_kernel_at_scale(monkeypatch):
         e.close()
 
 
+# ------------------------------------------------------------------------------------------------ round-3: the other BASELINE sizes
+BASELINE_SIZES = [("UR5ObsReach-v1", _abi.ENV_OBS, 16384), ("UR5OriReach-v1", _abi.ENV_ORI, 4096)]  # BASELINE.json configs[2], configs[1]
+
+
+@pytest.mark.parametrize("env_id,kind,n", BASELINE_SIZES)
+def test_step_parity_against_oracle_at_baseline_size(oracle, env_id, kind, n):
+    """BASELINE.json configs[2] / configs[1] at their own size, in the launch geometry the library picks for that size (Obs 16384:
+    24-env workgroups, one round; Ori 4096: 8-env workgroups): HIP path and oracle free-run from the same seed, every output of
+    every step (the 320-env tests above run another geometry)."""
+    steps = 12
+    env = make_vec(env_id, num_envs=n, seed=41)
+    orc = oracle.OracleEnv(kind, n, threads=min(16, os.cpu_count() or 1))
+    env.reset(seed=41)
+    orc.reset(seed=41)
+    torch.cuda.synchronize()
+    st = env.get_state()
+    for k in ("q", "goal", "obst_start", "obst_pos", "obst_quat"):
+        assert np.abs(st[k] - orc.buf[k]).max() < 1e-12, k
+    if kind != _abi.ENV_ORI:
+        link_dist_slack(oracle, st["link_dist"], orc.buf["link_dist"], orc.buf["q"], orc.buf["obst_pos"], orc.buf["obst_quat"])
+        env.buf["link_dist"].copy_(torch.from_numpy(orc.buf["link_dist"]).cuda())
+    rng = np.random.default_rng(41)
+    finished, unstable = 0, 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (n, 6)).astype(np.float32)
+        d, u = step_both(oracle, kind, env, orc, a, where=f"{env_id} N={n} step {t}")
+        finished += d
+        unstable += u
+    assert finished > 0.002 * n * steps   # episodes ended (collisions under a random policy): the auto-reset path ran at this size
+    assert unstable < 1e-3 * steps * n * 5 + 3
+    assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
+    env.close()
+
+
+@pytest.mark.parametrize("env_id,kind,n", BASELINE_SIZES)
+def test_full_size_properties_other_configs(env_id, kind, n):
+    """Size-independent properties at BASELINE.json's sizes of the two other single-GPU configs (the Dyn one: test_full_size_properties)."""
+    env = make_vec(env_id, num_envs=n, seed=0)
+    env.reset(seed=0)
+    torch.cuda.synchronize()
+    assert torch.all(env.buf["q"].T == torch.tensor([0.0, -1.5708, 0.0, -1.5708, 0.0, 0.0], dtype=torch.float64, device="cuda:0"))
+    g = env.buf["goal"]
+    zlo = -0.1 if kind == _abi.ENV_OBS else 0.0   # reach.py:248 / 151
+    assert g[0].min() >= 0.3 and g[0].max() <= 0.75 and g[2].min() >= zlo and g[2].max() <= 0.2
+    if kind == _abi.ENV_OBS:
+        assert env.buf["link_dist"].min() > 0.01     # no episode starts in contact (reach.py:324-326)
+    assert not env.buf["status"].any()
+    gen = torch.Generator(device="cuda:0").manual_seed(1)
+    acts = torch.rand((30, n, 6), generator=gen, device="cuda:0") * 2 - 1
+    ep0 = env.buf["episode_id"].clone()
+    for t in range(30):
+        obs, rew, term, trunc, info = env.step(acts[t])
+        done = term | trunc
+        sc = env.buf["step_count"]
+        assert torch.all(sc[done] == 0) and torch.all(sc[~done] >= 1)
+        assert torch.all(obs["observation"].abs() <= 10.0)  # Box(-10, 10) of core.py:241-247
+        assert torch.all(info["is_success"] == (term & ~info["collision"]))
+        assert torch.all(rew[info["collision"]] < -250.0)   # the -500 of a collision dominates both additive reward forms (+200 if it is also a success)
+    torch.cuda.synchronize()
+    assert (env.buf["episode_id"] > ep0).any()
+    assert not (env.buf["status"] & ~(_abi.STATUS_PENETRATION | _abi.STATUS_JOINT_LIMIT)).any()
+    # determinism: a second instance, same seed and actions, through urgym_rollout
+    env2 = make_vec(env_id, num_envs=n, seed=0)
+    env2.reset(seed=0)
+    env2.rollout(acts)
+    torch.cuda.synchronize()
+    for key in ("observation", "reward", "q", "step_count", "episode_id") + (("link_dist",) if kind == _abi.ENV_OBS else ()):
+        assert torch.equal(env.buf[key], env2.buf[key]), key
+    # batch-position independence: env 0's state in every slot -> every row steps identically
+    st = {k: v for k, v in env2.get_state().items()}
+    for k, v in st.items():
+        v[...] = v[..., :1]
+    env3 = make_vec(env_id, num_envs=n, seed=0, auto_reset=False)
+    env3.set_state(st)
+    env3.buf["observation"][:] = env2.buf["observation"][0]
+    obs, rew, term, trunc, _ = env3.step(acts[0, :1].expand(n, 6).contiguous())
+    torch.cuda.synchronize()
+    assert torch.all(obs["observation"] == obs["observation"][0]) and torch.all(rew == rew[0])
+    for e in (env, env2, env3):
+        e.close()
+
+
+@pytest.mark.parametrize("env_id,kind,n", BASELINE_SIZES)
+def test_inline_reset_is_bitwise_the_reset_kernel_other_configs(monkeypatch, env_id, kind, n):
+    """Obs 16384: the inline reset from prefetched episode records; Ori 4096: the goal draw inside the step kernel -- both must leave
+    exactly the bits the RESET kernel leaves (URGYM_PREFETCH=0), outputs and state, every step, past the common truncation step."""
+    steps = 110
+    envs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("URGYM_PREFETCH", flag)
+        e = make_vec(env_id, num_envs=n, seed=67)
+        e.reset(seed=67)
+        envs.append(e)
+    gen = torch.Generator(device="cuda").manual_seed(67)
+    keys = ["observation", "achieved_goal", "desired_goal", "reward", "terminated", "truncated", "is_success", "collision", "final_observation",
+            "status", "q", "goal", "step_count", "episode_id"]
+    if kind != _abi.ENV_ORI:
+        keys += ["obst_start", "obst_end", "obst_pos", "obst_quat", "obst_vel", "link_dist"]
+    for t in range(steps):
+        a = torch.rand((n, 6), device="cuda", generator=gen) * 2 - 1
+        for e in envs:
+            e.step(a)
+        torch.cuda.synchronize()
+        for k in keys:
+            x, y = envs[0].buf[k], envs[1].buf[k]
+            if k == "final_observation":
+                m = (envs[0].buf["terminated"] | envs[0].buf["truncated"]).bool()
+                x, y = x[m], y[m]
+            assert torch.equal(x, y) or torch.equal(torch.nan_to_num(x.double()), torch.nan_to_num(y.double())), (k, t)
+    for e in envs:
+        e.close()
+
+
 # ------------------------------------------------------------------------------------------------ round-2 additions
 def test_pose_distances_against_reference_utils_fixtures():
     """tests/golden/utils_golden.json was produced by the reference's OWN UR_gym/utils.py (gen_utils_golden.py): every pair of

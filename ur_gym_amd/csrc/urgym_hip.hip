@@ -832,6 +832,11 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       exact = ((item >> 16) & 1) != 0;
       lb = (item >> 10) & 7;
       la = (item >> 13) & 7;
+      // An item is decoded from a ticket number or a pair bit.  Whatever produced it, nothing below may index with fields that are
+      // out of range: e picks the env slot (s_env, the per-env rows of the global scratch arrays), lb / la pick hull tables.  (Round 2
+      // lost a GPU to an experiment whose ticket-order list fed this decoder -- profiles/r3/EXPERIMENTS.md; the order is gone, the
+      // bound stays.)
+      if (e >= E || lb < 1 || lb > 6 || (kind == Q_SELF && (la < 1 || la > 6))) return false;
       const int n = s_env[e];
       if (n < 0) return false;
       const bool cached = (MODE == MODE_STEP) && p1_ok && P.sc_scratch != nullptr;  // (then s_env already carries P1's verdict on the joints)
@@ -1588,6 +1593,7 @@ struct Handle {
   int big_blocks = 0, tail_envs = 0;  // two-tier geometry of the step launch: the first big_blocks workgroups serve step_envs, the rest tail_envs
   int reset_envs = 4;   // envs per workgroup of the auto-reset kernel (latency-bound: few envs, spread wide)
   char err[512] = {0};
+  bool launch_refused = false;  // a launch was not issued because its geometry failed validation (err says why)
   // timing
   bool timing = false;
   int timing_every = 1;   // time every k-th step (an event pair costs the stream ~6 us: sampling keeps the measurement out of the measured)
@@ -1718,6 +1724,16 @@ KParams make_params(Handle* h, int copy_final) {
   return P;
 }
 
+// A STEP grid must cover env 0 .. n-1 exactly once with workgroups of at most STEP_MAX_ENVS envs: the kernel derives every per-env
+// index (LDS slots, rows of the scratch arrays, observation rows) from (workgroup index, P.envs, P.big_blocks, P.envs_tail).
+bool step_geometry_ok(const KParams& P, long n, long blocks) {
+  if (P.envs < 1 || P.envs > STEP_MAX_ENVS || blocks < 1) return false;
+  if (P.envs_tail == 0) return (blocks - 1) * P.envs < n && blocks * P.envs >= n;
+  if (P.envs_tail < 1 || P.envs_tail > STEP_MAX_ENVS || P.big_blocks < 1 || P.big_blocks >= blocks) return false;
+  const long covered_before_last = (long)P.big_blocks * P.envs + (blocks - P.big_blocks - 1) * P.envs_tail;
+  return covered_before_last < n && covered_before_last + P.envs_tail >= n;
+}
+
 template <int MODE>
 void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream_t s, long items = -1) {
   const int cap = (MODE == MODE_PREFETCH) ? PREFETCH_MAX_ENVS : ((MODE == MODE_STEP) ? STEP_MAX_ENVS : MAX_ENVS);
@@ -1731,6 +1747,7 @@ void launch_mode(Handle* h, KParams P, const float* actions, int envs, hipStream
     blocks = h->big_blocks + (items - (long)h->big_blocks * envs + h->tail_envs - 1) / h->tail_envs;
   }
   dim3 grid((unsigned)blocks), block(THREADS);
+  if (MODE == MODE_STEP && !step_geometry_ok(P, items, blocks)) { snprintf(h->err, sizeof(h->err), "step launch geometry does not cover the envs exactly once"); h->launch_refused = true; return; }
   // which launches can consume a penetration depth: see need_epa in the kernel
   const bool epa = (MODE != MODE_STEP) || !h->cfg.check_collision;
   switch (h->cfg.env_kind) {
@@ -1770,6 +1787,7 @@ void launch_fused(Handle* h, KParams Ps, KParams Pr, const float* actions, hipSt
   else if (h->burst_due()) refill_blocks = full;
   if (refill_blocks > full) refill_blocks = full;
   dim3 grid((unsigned)(step_blocks + refill_blocks)), block(THREADS);
+  if (!step_geometry_ok(Ps, n, step_blocks)) { snprintf(h->err, sizeof(h->err), "step launch geometry does not cover the envs exactly once"); h->launch_refused = true; return; }
   const bool epa = !h->cfg.check_collision;  // (which STEP launches can consume a penetration depth: see need_epa in the kernel)
   const int sb = (int)step_blocks;
   switch (h->cfg.env_kind) {
@@ -1875,6 +1893,7 @@ int do_step(Handle* h, const float* actions, hipStream_t s) {
     }
     h->parity = nxt;
   }
+  if (h->launch_refused) { h->launch_refused = false; return URGYM_ERR_STATE; }
   if (h->steps_since_full_reset >= 0) h->steps_since_full_reset++;
   h->pp ^= 1;
   HIP_TRY(h, hipGetLastError());
