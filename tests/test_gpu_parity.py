@@ -723,7 +723,7 @@ def test_step_parity_against_oracle_at_baseline_size(oracle, env_id, kind, n):
         d, u = step_both(oracle, kind, env, orc, a, where=f"{env_id} N={n} step {t}")
         finished += d
         unstable += u
-    assert finished > 0.002 * n * steps   # episodes ended (collisions under a random policy): the auto-reset path ran at this size
+    assert finished >= 10   # episodes ended (collisions under a random policy): the auto-reset path ran at this size
     assert unstable < 1e-3 * steps * n * 5 + 3
     assert np.array_equal(np_(env.buf["status"]), orc.buf["status"])
     env.close()
