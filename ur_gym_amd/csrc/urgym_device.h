@@ -492,9 +492,12 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
   int n = r.n + 1;
   URGYM_TRIP_MARK(2);
   // ---- closest point of the simplex to the origin + vertex reduction
+  // (the vertices the closest point rests on are kept as ONE per-lane bit mask, bit i = vertex i: four booleans that are live across
+  //  the face loop would be four lane masks in scalar registers, merged with three scalar instructions each per pass -- and the loop
+  //  is short of scalar registers)
   D3 nv = d3(0, 0, 0);
   bool valid = true;
-  bool ua = true, ub = true, uc = true, ud = true;
+  int used = 15;
   bool reduce = true;
   if (n == 1) {
     nv = w;
@@ -504,16 +507,16 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
     D3 s0 = W0;
     D3 e = w - s0;
     double t = -dot(e, s0);
+    used = 3;
     if (t > 0.0) {
       double ee = dot(e, e);
       if (t < ee) t /= ee;
-      else { t = 1.0; ua = false; }
+      else { t = 1.0; used = 2; }
     } else {
       t = 0.0;
-      ub = false;
+      used = 1;
     }
     nv = s0 + e * t;
-    uc = ud = false;
   } else {
     // n == 3: the triangle itself.  n == 4: the faces in Bullet's order ABC|D, ACD|B, ADB|C, BDC|A, each only when the
     // origin lies on its outer side.  Two passes: (1) the four plane tests, which every lane with a tetrahedron needs,
@@ -547,8 +550,7 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
     }
     URGYM_TRIP_MARK(6);
     double best = 1.0e300;
-    bool any_out = false;
-    ua = ub = uc = ud = false;
+    used = -1;  // no face evaluated yet
 #pragma unroll 1
     while (todo) {
       const int f = __builtin_ctz((unsigned)todo);
@@ -560,18 +562,16 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
       URGYM_LANE_MARK(5);
       const D3 pt = tri_closest(a, b, c, m3 URGYM_PROF_PASS(r.clk));
       const double l = len2(pt);
-      if (!any_out || l < best) {
+      if (used < 0 || l < best) {
         best = l;
         nv = pt;
-        const int used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
-        ua = used & 1; ub = used & 2; uc = used & 4; ud = used & 8;
+        used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
       }
-      any_out = true;
     }
     if (degen) {
       valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
       reduce = false;
-    } else if (!any_out) {
+    } else if (used < 0) {
       nv = d3(0, 0, 0);  // origin inside the tetrahedron
       reduce = false;
     }
@@ -580,10 +580,10 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
   if (reduce) {
     URGYM_LANE_MARK(13);
     // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
-    if (n >= 4 && !ud) { n--; }
-    if (n >= 3 && !uc) { n--; stw(T, 2, ldw(T, n)); }
-    if (n >= 2 && !ub) { n--; stw(T, 1, ldw(T, n)); }
-    if (n >= 1 && !ua) { n--; stw(T, 0, ldw(T, n)); }
+    if (n >= 4 && !(used & 8)) { n--; }
+    if (n >= 3 && !(used & 4)) { n--; stw(T, 2, ldw(T, n)); }
+    if (n >= 2 && !(used & 2)) { n--; stw(T, 1, ldw(T, n)); }
+    if (n >= 1 && !(used & 1)) { n--; stw(T, 0, ldw(T, n)); }
   }
   r.n = n;
   if (!valid) { gjk_finish(r, true, 3); return; }
