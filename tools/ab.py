@@ -3,7 +3,7 @@
 library (URGYM_LIB) and environment switches; variants are interleaved over the repetitions so that clock drift hits all alike.
 
     python tools/ab.py --out gpurun_out/exp_x/results.jsonl --reps 2 \
-        --variant base::                                  (name:library:ENV=V,ENV=V)
+        --variant base::                                  (name:library:ENV=V;ENV=V)
         --variant res2:ur_gym_amd/csrc/build/liburgym_res2.so:URGYM_STEP_ENVS=128 \
         -- --num-envs 65536                                (arguments after -- go to bench.py)
 
@@ -22,7 +22,7 @@ os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
 variants = []
 for v in args.variant:
     name, lib, envs = (v.split(":") + ["", ""])[:3]
-    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    env = dict(kv.split("=", 1) for kv in envs.split(";") if kv)  # ENV=V;ENV=V (values may hold commas)
     if lib:
         env["URGYM_LIB"] = lib if os.path.isabs(lib) else os.path.join(ROOT, lib)
     variants.append((name, env))
