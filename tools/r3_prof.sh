@@ -17,13 +17,13 @@ prof_cfg() {  # <short> <label> <bench args...>
   pmc() { local name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $P/$name -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline "${BARGS[@]}" > $P/$name.log 2>&1 || { echo "$short $name failed"; return 1; }; }
   BARGS=("$@")
   pmc sq SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY || return 1
-  pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT || return 1
+  pmc sq2 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INSTS_FLAT || return 1
   pmc tcc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum || return 1
   pmc fetch FETCH_SIZE || return 1
   pmc write WRITE_SIZE || return 1
   find $P -name "*.csv" -size +20M -delete
   cp $(find $P/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$short.csv 2>/dev/null
-  SPECS+=("$label=$P")
+  SPECS+=("$label::$P")
   echo "$short done"
 }
 rocprofv3 -L > $OUT/counters_avail.txt 2>&1 || true
@@ -39,12 +39,12 @@ if [ $rc -eq 0 ]; then
   lone() { local name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $P/$name -- python3 $R/bench.py --steps 12 --warmup 3 --no-cpu-baseline --num-envs 728 > $P/$name.log 2>&1 || echo "lone $name failed"; }
   lone a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
   lone b SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM
-  lone c SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_IFETCH
+  lone c SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_FLAT SQ_INSTS_FLAT SQ_IFETCH
   unset URGYM_STEP_ENVS
-  SPECS+=("UR5DynReach-v1 N=728 lone wave per SIMD=$P")
+  SPECS+=("UR5DynReach-v1 N=728 lone wave per SIMD::$P")
 fi
 python3 $R/tools/summarize_pmc.py --elf $R/ur_gym_amd/csrc/build/resource_usage.txt "${SPECS[@]}" > $OUT/pmc_summary.json 2> $OUT/pmc_summary.err
 head -c 400 $OUT/pmc_summary.json; echo
-# raw per-pass directories are large: keep the condensed files only
-rm -rf $OUT/dyn65536 $OUT/obs16384 $OUT/ori4096 $OUT/ori4096nc $OUT/lone
+# raw per-pass directories are large: keep the condensed files only (once the summary really holds kernels)
+grep -q "env_step_fused" $OUT/pmc_summary.json && rm -rf $OUT/dyn65536 $OUT/obs16384 $OUT/ori4096 $OUT/ori4096nc $OUT/lone
 exit $rc

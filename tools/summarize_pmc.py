@@ -2,7 +2,7 @@
 """Summarise rocprofv3 output of tools/r3_prof.sh: one JSON object per profiled CONFIGURATION, keyed by the REAL kernel names
 (`env_step_fused<2, false>`, `env_kernel<0, 0, false>`, ...), mean counter values per launch.
 
-    python tools/summarize_pmc.py [--elf build/resource_usage.txt] "<label>=<dir>" ["<label>=<dir>" ...]
+    python tools/summarize_pmc.py [--elf build/resource_usage.txt] "<label>::<dir>" ["<label>::<dir>" ...]
 
 <dir> holds the passes of one configuration: trace/ (--kernel-trace --stats) and one directory per --pmc group.
 Derived figures (MI355X_MICROARCH.md): SQ_ACTIVE_INST_* count quad-cycles; SQ_BUSY_CYCLES is summed over the 32 shader engines.
@@ -38,7 +38,7 @@ def short(name):
 
 out = {}
 for spec in args:
-    label, d = spec.split("=", 1)
+    label, d = spec.split("::", 1)
     cfg = {}
     for f in glob.glob(f"{d}/*/*/*counter_collection.csv") + glob.glob(f"{d}/*/*counter_collection.csv"):
         df = pd.read_csv(f)
