@@ -465,13 +465,19 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
   {
     // A a hull: its cell code is requested first, the support of B (for the cylinder a square root and a division: a dependent chain
     // of its own) is evaluated while that load travels, the candidates of A's cell are fetched and ranked afterwards
-    const D3 dA = rotT(T, -r.v);
+    // the pose of A is read from LDS ONCE per iteration (direction transform and point transform use the same nine numbers): one LDS
+    // round trip instead of two on the dependent chain; the twelve doubles stay in registers across the support call
+    X3 TX;
+#pragma unroll
+    for (int k = 0; k < 9; k++) TX.r[k] = T.at(k);
+    TX.t = d3(T.at(9), T.at(10), T.at(11));
+    const D3 dA = rotT(TX, -r.v);
     int rec = 0;
     if (A.type == SH_HULL) rec = g.cell[A.hull * DIRMAP_CELLS + dirmap_cell(dA)];
     const D3 q = support_local(g, B, r.v URGYM_PROF_PASS(r.clk));
     URGYM_TRIP_MARK(2);
     const D3 sA = (A.type == SH_HULL) ? hull_support_from(g, rec, dA URGYM_PROF_PASS(r.clk)) : support_local(g, A, dA URGYM_PROF_PASS(r.clk));
-    const D3 p = apply(T, sA);
+    const D3 p = apply(TX, sA);
     URGYM_TRIP_MARK(1);
     w = p - q;
   }
