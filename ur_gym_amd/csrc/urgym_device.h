@@ -461,6 +461,9 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
                                             double verdict_d = 0.0) {
   const double REL_ERROR2 = 1.0e-12;
   const double EPS = 2.220446049250313e-16;
+  // the (up to three) vertices already in the simplex, requested together with the pose: their LDS round trip runs under the support
+  // calls instead of after them (a slot at or beyond r.n holds stale data and is masked where it matters)
+  const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
   D3 w;
   {
     // A a hull: its cell code is requested first, the support of B (for the cylinder a square root and a division: a dependent chain
@@ -485,7 +488,6 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
   if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { URGYM_LANE_MARK(18); gjk_finish(r, true, 10); return; }
   // the (up to three) vertices already in the simplex: read once, together -- the duplicate test below, the segment case and the
   // plane tests of the tetrahedron all use them (a slot at or beyond r.n holds stale data and is masked where it matters)
-  const D3 W0 = ldw(T, 0), W1 = ldw(T, 1), W2 = ldw(T, 2);
   {
     // (bitwise on purpose: three independent comparisons, no short-circuit branches)
     const bool in = (((int)(r.n > 0) & (int)(len2(W0 - w) <= 1e-12)) | ((int)(r.n > 1) & (int)(len2(W1 - w) <= 1e-12)) |
