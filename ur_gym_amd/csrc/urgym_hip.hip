@@ -551,7 +551,9 @@ struct EnvLds {
   uint32_t s_pairs[ME];         // culling survivors: one bit per table / track / self pair (PAIR_* below)
   int s_flags[ME];              // status bits | COLL_BIT
   int s_env[ME];                // global env id of slot e, -1 = empty slot, <= -2: non-finite joints
-  int s_ticket, s_pending;      // next obstacle-query ticket; number of unclaimed pair bits
+  // the four words of the work pool, adjacent and 16-byte aligned so that the polling of a loop trip is ONE LDS read:
+  alignas(16) int s_ticket;     // next obstacle-query ticket
+  int s_pending;                // number of unclaimed pair bits
   int s_p1done;                 // STEP: the per-env phase has published its pair masks
   int s_left;                   // waves that have left the work pool (the EPA service polls it)
   int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
@@ -997,9 +999,14 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       }
       SECTION(4);
       // (atomic loads: other waves change both words while this one polls them; a plain read could legally be hoisted)
-      const bool more_tickets = __hip_atomic_load(&s_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < n_tickets;
-      const bool p1_published = (MODE != MODE_STEP) || __hip_atomic_load(&s_p1done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= G;
-      const bool more_pairs = __hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0;  // (read AFTER the acquire)
+      // one 16-byte LDS read of the pool's words (three dependent round trips when they were polled one by one), then the acquire:
+      // what the P1 lanes wrote before they counted themselves in s_p1done (pair masks, the set-up cache) is visible to what follows
+      typedef int pool_words __attribute__((ext_vector_type(4)));
+      const pool_words pool = *(volatile URGYM_LDS pool_words*)(URGYM_LDS void*)&s_ticket;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const bool more_tickets = pool.x < n_tickets;
+      const bool p1_published = (MODE != MODE_STEP) || pool.z >= G;
+      const bool more_pairs = pool.y > 0;
       if (MODE == MODE_STEP) p1_ok = p1_published;
       // drawing an item costs the whole wave a set-up (FK + operands), so idle lanes
       // draw together: once REFILL_MIN of them are waiting, or when none is busy any more
