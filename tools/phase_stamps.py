@@ -69,7 +69,7 @@ print(f"  time per loop trip: {us(loop.sum()) / trips.sum():.2f} us")
 if not args.reset_kernel:
     sect = np.concatenate([st[:, :, 12:18], st[:, :, 20:24]], axis=2).astype(np.float64)
     # section i ends at mark i (urgym_device.h URGYM_TRIP_MARK / the kernel's SECTION): 0 is never marked
-    names = ("(unused)", "support of A (pose transform, hull climb)", "support of B, exits, simplex vertex stored",
+    names = ("(unused)", "support of A: candidate record(s), point transform", "pose, cell code request, support of B | exits, vertex stored",
              "vertex reduction, convergence tests", "result handling", "polling, draw, set-up",
              "simplex front: segment case / plane tests", "simplex: face evaluations (triangle routine)", "(unused)", "(unused)")
     tot = sect.sum()
