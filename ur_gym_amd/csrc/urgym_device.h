@@ -438,8 +438,9 @@ __device__ __forceinline__ void gjk_begin(GjkRun& r, D3 v0) {
   r.clk = nullptr;
 #endif
 }
-// exit of the search: what Bullet does after its loop (checkSimplex / degenerate cases)
-__device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int degenerate) {
+// exit of the search: what Bullet does after its loop (checkSimplex / degenerate cases).  separated: the exit was the early-out on a
+// separating axis (Bullet's degenerate case 10)
+__device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, bool separated) {
   const double REL_ERROR2 = 1.0e-12;
   const double l2 = len2(r.v);
   r.done = true;
@@ -448,7 +449,7 @@ __device__ __forceinline__ void gjk_finish(GjkRun& r, bool check_simplex, int de
     r.core = 0.0;
     return;
   }
-  if (degenerate == 10) r.info |= GJK_SEPARATED;
+  if (separated) r.info |= GJK_SEPARATED;
   r.core = sqrt(l2);
 }
 // one iteration of btGjkPairDetector's loop.  max_d: Bullet's early-out distance of this query (handed in per call rather than
@@ -484,18 +485,20 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
     URGYM_TRIP_MARK(1);
     w = p - q;
   }
+  // Every exit of the iteration only RECORDS that and how the search ends (fin: bit 0 = ends, bit 1 = without the simplex check, i.e.
+  // overlapping cores / iteration cap, bit 2 = on a separating axis); the bookkeeping of an ended search -- a square root among it --
+  // runs once, at the bottom, for all lanes that end in this trip, instead of once per exit that some lane happens to take.
+  int fin = 0;
   const double delta = dot(r.v, w);
-  if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { URGYM_LANE_MARK(18); gjk_finish(r, true, 10); return; }
-  // the (up to three) vertices already in the simplex: read once, together -- the duplicate test below, the segment case and the
-  // plane tests of the tetrahedron all use them (a slot at or beyond r.n holds stale data and is masked where it matters)
-  {
+  if (delta > 0.0 && delta * delta > r.sq * (max_d * max_d)) { URGYM_LANE_MARK(18); fin = 1 | 4; }
+  if (fin == 0) {
     // (bitwise on purpose: three independent comparisons, no short-circuit branches)
     const bool in = (((int)(r.n > 0) & (int)(len2(W0 - w) <= 1e-12)) | ((int)(r.n > 1) & (int)(len2(W1 - w) <= 1e-12)) |
                      ((int)(r.n > 2) & (int)(len2(W2 - w) <= 1e-12))) != 0;
-    if (in) { URGYM_LANE_MARK(18); gjk_finish(r, true, 1); return; }
+    const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;
+    if (in || f0 <= f1) { URGYM_LANE_MARK(18); fin = 1; }
   }
-  const double f0 = r.sq - delta, f1 = r.sq * REL_ERROR2;
-  if (f0 <= f1) { URGYM_LANE_MARK(18); gjk_finish(r, true, (f0 <= 0.0) ? 2 : 11); return; }
+  if (fin == 0) {
   stw(T, r.n, w);
   int n = r.n + 1;
   URGYM_TRIP_MARK(2);
@@ -594,16 +597,24 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
     if (n >= 1 && !(used & 1)) { n--; stw(T, 0, ldw(T, n)); }
   }
   r.n = n;
-  if (!valid) { gjk_finish(r, true, 3); return; }
-  const double nsq = len2(nv);
-  if (nsq < REL_ERROR2) { r.v = nv; gjk_finish(r, true, 6); return; }
-  if (nsq <= verdict_d * verdict_d) { r.v = nv; r.info |= GJK_CLOSE; gjk_finish(r, true, 14); return; }
-  const double prev = r.sq;
-  r.sq = nsq;
-  if (prev - nsq <= EPS * prev) { gjk_finish(r, true, 12); return; }
-  r.v = nv;
-  if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; gjk_finish(r, false, 0); return; }
-  if (n == 4) { gjk_finish(r, false, 13); return; }
+  if (!valid) fin = 1;  // sliver tetrahedron
+  else {
+    const double nsq = len2(nv);
+    if (nsq < REL_ERROR2) { r.v = nv; fin = 1; }
+    else if (nsq <= verdict_d * verdict_d) { r.v = nv; r.info |= GJK_CLOSE; fin = 1; }
+    else {
+      const double prev = r.sq;
+      r.sq = nsq;
+      if (prev - nsq <= EPS * prev) fin = 1;  // no progress: the previous v stands
+      else {
+        r.v = nv;
+        if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; fin = 3; }
+        else if (n == 4) fin = 3;  // the origin is inside the tetrahedron
+      }
+    }
+  }
+  }  // fin == 0 before the simplex step
+  if (fin) gjk_finish(r, !(fin & 2), (fin & 4) != 0);
 }
 
 
