@@ -557,6 +557,11 @@ struct EnvLds {
   int s_p1done;                 // STEP: the per-env phase has published its pair masks
   int s_left;                   // waves that have left the work pool (the EPA service polls it)
   int s_key[(MODE != MODE_STEP) ? ME : 1];  // RESET: the env's new episode id; PREFETCH: the entry's episode
+  // STEP: what a query's kind decides, as a table -- row kind | exact << 2 = {core half dims of B (3), Bullet's early-out distance, the
+  // verdict distance (0: the distance itself is wanted)}: five LDS reads at the top of a trip, beside the pose, instead of sixty
+  // selects and literal moves per trip that re-derived them (they may not live in registers across the search: DESIGN.md "toolchain
+  // hazards" (1), and the register budget).  (The fused launch's union is sized by the PREFETCH layout: these bytes are free.)
+  double s_kind[(MODE == MODE_STEP) ? 8 : 1][5];
   // ... and per-lane slots
   double s_pose[GJK_SLOT_DOUBLES][THREADS];  // GJK operand: pose of shape A in B's frame + the simplex
 #ifdef URGYM_STAMPS
@@ -634,6 +639,18 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
     if (first >= list_count) return;  // uniform for the whole workgroup
   }
   if (tid == 0) { s_ticket = THREADS; s_pending = 0; s_p1done = 0; s_left = 0; }
+  if (MODE == MODE_STEP && tid < 8) {
+    const int k = tid & 3, ex = tid >> 2;
+    const bool tbl = (k == Q_TABLE);
+    const double msum = M_HULL + ((k == 3) ? M_CYL : ((k == Q_SELF) ? M_HULL : (tbl ? M_TABLE : M_TRACK)));
+    const bool wants = (k == 3) || ex;
+    const double verdict = wants ? 0.0 : msum + cfg.collision_margin;
+    L.s_kind[tid][0] = (k == 3) ? (CYL_R - M_CYL) : (tbl ? (TABLE_HX - M_TABLE) : (TRACK_HX - M_TRACK));
+    L.s_kind[tid][1] = (k == 3) ? (CYL_R - M_CYL) : (tbl ? (TABLE_HY - M_TABLE) : (TRACK_HY - M_TRACK));
+    L.s_kind[tid][2] = (k == 3) ? (0.5 * CYL_H - M_CYL) : (tbl ? (TABLE_HZ - M_TABLE) : (TRACK_HZ - M_TRACK));
+    L.s_kind[tid][3] = wants ? msum + 0.02 + 5.0 : verdict;
+    L.s_kind[tid][4] = verdict;
+  }
   // URGYM_LINK_DIST_WORKBENCH: link_dist[i] = min over obstacle, table, track -- three exact queries per link race for the
   // cell, which therefore holds the order-preserving int64 image of the distance (sortable()); +inf is its own image
   const bool workbench = (KIND != URGYM_ENV_ORI) && cfg.link_dist_scope == URGYM_LINK_DIST_WORKBENCH;
@@ -970,9 +987,18 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
         // exact queries (link distances): Bullet's early-out distance of getClosestPoints(distance = 5.0).  Boolean queries ("closer
         // than the contact margin?", check_collision): both bounds of the search are compared with the margin itself -- the search
         // stops as soon as either decides, with the verdict Bullet reaches after converging (pyb_setup.py:402-422)
-        const bool wants_distance = (kind == 3 || exact);
-        const double verdict_d = wants_distance ? 0.0 : margin_sum() + cfg.collision_margin;
-        gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d);
+        if (MODE == MODE_STEP) {
+          const URGYM_LDS double* row = (const URGYM_LDS double*)(URGYM_LDS void*)&L.s_kind[kind | ((int)exact << 2)][0];
+          ShapeDesc sb;
+          sb.type = (kind == 3) ? SH_CYLZ : ((kind == Q_SELF) ? SH_HULL : SH_BOX);
+          sb.hull = lb - 1;
+          sb.hx = row[0]; sb.hy = row[1]; sb.hz = row[2];
+          gjk_iterate(run, P.graph, shape_a(), pose_slot, sb, row[3], row[4]);
+        } else {
+          const bool wants_distance = (kind == 3 || exact);
+          const double verdict_d = wants_distance ? 0.0 : margin_sum() + cfg.collision_margin;
+          gjk_iterate(run, P.graph, shape_a(), pose_slot, shape_b(), wants_distance ? margin_sum() + 0.02 + 5.0 : verdict_d, verdict_d);
+        }
         SECTION(3);
         if (run.done) {
 #ifdef URGYM_STAMPS
