@@ -153,3 +153,25 @@ def test_lazy_info_dict_semantics():
     assert dict(other) == {"a": 1, "b": 2} and sorted(other) == ["a", "b"] and list(other.values()) == [1, 2]
     with pytest.raises(KeyError):
         info["nope"]
+
+
+def test_bench_reads_the_committed_counters_by_configuration():
+    """bench.py's roofline.traffic / valu_issue come from profiles/r3/pmc_summary.json, keyed by configuration and by the REAL kernel
+    name (round 2 filed the fused launch under a legacy key): every BASELINE single-GPU configuration must be there, and the dominant
+    kernel of the obstacle envs must be the fused step launch."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for env_id, n, nc, ro, kernel in (("UR5DynReach-v1", 65536, False, False, "env_step_fused<2, false>"),
+                                      ("UR5ObsReach-v1", 16384, False, False, "env_step_fused<1, true>"),
+                                      ("UR5OriReach-v1", 4096, False, False, "env_kernel<0, 0, false>"),
+                                      ("UR5OriReach-v1", 4096, True, True, "env_kernel<0, 0, false>")):
+        name, traffic, valu = bench.profiled_counters(bench.config_label(env_id, n, nc, ro))
+        assert name == kernel, (env_id, name)
+        assert traffic["corrected"] > traffic["uncorrected"] > 0
+        assert 0.0 < valu["valu_frac"] < 1.0 and abs(valu["valu_frac"] - valu["busy_fraction_of_simd_cycles"] * valu["lane_utilisation"]) < 1e-12
+        assert valu["vgprs_elf"] in (163, 168)
+    assert bench.profiled_counters("no such configuration") == (None, None, None)
+    assert bench.INFORMATIONAL_BITS == 8 | 32
