@@ -270,29 +270,45 @@ struct HullMap {
   const CandRec* __restrict__ recs;           // candidate records, shared by the cells with the same candidate set
   const unsigned short* __restrict__ cell;    // [6 hulls][6 faces][DIRMAP_G][DIRMAP_G] -> first record of the cell's list
 };
-// cell of a direction.  float32 on purpose: the host builds every cell's list for the cell inflated by far more than this
-// arithmetic can err (margin 1e-5 of the face's [-1, 1] square against ~1e-7), so a direction that lands in a neighbouring cell
-// by rounding still finds its support vertex listed there.
+// cell of a direction.  The cube map is the hardware's: V_CUBEID / V_CUBESC / V_CUBETC / V_CUBEMA_F32 (the texture unit's cube-map
+// addressing, four instructions) give the face 0..5 = +x, -x, +y, -y, +z, -z, the two in-face coordinates and twice the major
+// component; (sc, tc) / |ma| + 1/2 in [0, 1] then indexes the G x G cells of the face.  Face conventions (ISA manual; mirrored by
+// cube_face() below, which the host uses to BUILD the table and the CPU harness to look it up):
+//   major axis: z if |z| >= |x| and |z| >= |y|, else y if |y| >= |x|, else x
+//   +x: sc = -z, tc = -y   -x: sc = z, tc = -y   +y: sc = x, tc = z   -y: sc = x, tc = -z   +z: sc = x, tc = -y   -z: sc = -x, tc = -y
+// float32 on purpose: the host builds every cell's list for the cell inflated by far more than this arithmetic can err (margin 1e-5
+// of the face's [-1, 1] square against ~1e-7), so a direction that lands in a neighbouring cell -- or, on an exact tie of two
+// components, on the neighbouring FACE -- by rounding still finds its support vertex listed there.
+struct CubeFace { int axis, au, av; double s, su, sv; };  // direction of in-face point (u, v): d[axis] = s, d[au] = su u, d[av] = sv v
+__device__ __forceinline__ CubeFace cube_face(int face) {
+  switch (face) {
+    case 0: return CubeFace{0, 2, 1, 1.0, -1.0, -1.0};
+    case 1: return CubeFace{0, 2, 1, -1.0, 1.0, -1.0};
+    case 2: return CubeFace{1, 0, 2, 1.0, 1.0, 1.0};
+    case 3: return CubeFace{1, 0, 2, -1.0, 1.0, -1.0};
+    case 4: return CubeFace{2, 0, 1, 1.0, 1.0, -1.0};
+    default: return CubeFace{2, 0, 1, -1.0, -1.0, -1.0};
+  }
+}
 __device__ __forceinline__ int dirmap_cell(D3 d) {
   const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
-  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
-  const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
-  const float m = axis == 0 ? x : (axis == 1 ? y : z);
-  const float u = axis == 0 ? y : (axis == 1 ? z : x);
-  const float v = axis == 0 ? z : (axis == 1 ? x : y);
-  float am = fabsf(m);
-  if (!(am > 0.0f)) am = 1.0f;
 #ifdef URGYM_HOST_HARNESS
-  const float inv = 1.0f / am;
+  const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+  float id, sc, tc, ma;
+  if (az >= ax && az >= ay) { id = z < 0.0f ? 5.0f : 4.0f; sc = z < 0.0f ? -x : x; tc = -y; ma = 2.0f * z; }
+  else if (ay >= ax) { id = y < 0.0f ? 3.0f : 2.0f; sc = x; tc = y < 0.0f ? -z : z; ma = 2.0f * y; }
+  else { id = x < 0.0f ? 1.0f : 0.0f; sc = x < 0.0f ? z : -z; tc = -y; ma = 2.0f * x; }
+  const float inv = 1.0f / fabsf(ma);
 #else
-  const float inv = __builtin_amdgcn_rcpf(am);  // (1 ulp: covered by the inflation of the cells)
+  const float id = __builtin_amdgcn_cubeid(x, y, z), sc = __builtin_amdgcn_cubesc(x, y, z), tc = __builtin_amdgcn_cubetc(x, y, z);
+  const float ma = __builtin_amdgcn_cubema(x, y, z);
+  const float inv = __builtin_amdgcn_rcpf(fabsf(ma));  // (1 ulp: covered by the inflation of the cells)
 #endif
-  int iu = (int)((u * inv + 1.0f) * (0.5f * DIRMAP_G));
-  int iv = (int)((v * inv + 1.0f) * (0.5f * DIRMAP_G));
+  int iu = (int)((sc * inv + 0.5f) * (float)DIRMAP_G);   // (a zero direction gives NaN -> 0: any cell will do, nothing is searched with it)
+  int iv = (int)((tc * inv + 0.5f) * (float)DIRMAP_G);
   iu = iu < 0 ? 0 : (iu > DIRMAP_G - 1 ? DIRMAP_G - 1 : iu);
   iv = iv < 0 ? 0 : (iv > DIRMAP_G - 1 ? DIRMAP_G - 1 : iv);
-  const int face = axis * 2 + (m < 0.0f ? 1 : 0);
-  return (face * DIRMAP_G + iv) * DIRMAP_G + iu;
+  return ((int)id * DIRMAP_G + iv) * DIRMAP_G + iu;
 }
 
 // d . v evaluated exactly like the oracle's scan ((x*dx + y*dy) + z*dz, no fused ops) so that near-tied vertices are

@@ -64,8 +64,9 @@ inline HostTables make_host_tables() {
     T.ids.reserve((size_t)G * G * 2);
     const int v0 = UR5E_HULL_OFFSET[h], v1 = UR5E_HULL_OFFSET[h + 1];
     std::vector<int> mark(v1 - v0, -1), queue, parent;
-    const int axis = face / 2, au = (axis + 1) % 3, av = (axis + 2) % 3;
-    const double s = (face & 1) ? -1.0 : 1.0;
+    const CubeFace cf = cube_face(face);  // the hardware's cube-map conventions (urgym_device.h dirmap_cell)
+    const int axis = cf.axis, au = cf.au, av = cf.av;
+    const double s = cf.s, su = cf.su, sv = cf.sv;
     int cur = -1, row_start = -1, stamp = 0;
     for (int iv = 0; iv < G; iv++) {
       cur = row_start;
@@ -73,7 +74,7 @@ inline HostTables make_host_tables() {
         const double ulo = 2.0 * iu / G - 1.0 - CellCandidates::MARGIN, uhi = 2.0 * (iu + 1) / G - 1.0 + CellCandidates::MARGIN;
         const double vlo = 2.0 * iv / G - 1.0 - CellCandidates::MARGIN, vhi = 2.0 * (iv + 1) / G - 1.0 + CellCandidates::MARGIN;
         double d[3];
-        d[axis] = s; d[au] = 0.5 * (ulo + uhi); d[av] = 0.5 * (vlo + vhi);
+        d[axis] = s; d[au] = su * 0.5 * (ulo + uhi); d[av] = sv * 0.5 * (vlo + vhi);
         auto value = [&](int k) { return (UR5E_HULL_VERTS[k][0] * d[0] + UR5E_HULL_VERTS[k][1] * d[1]) + UR5E_HULL_VERTS[k][2] * d[2]; };
         if (cur < 0) {  // first cell of the face: scan
           cur = v0;
@@ -93,7 +94,7 @@ inline HostTables make_host_tables() {
         // half-plane of "p is at least as good as n" in the (u, v) plane of this face
         auto coef = [&](int p, int n, double& a, double& b, double& c) {
           const double e[3] = {UR5E_HULL_VERTS[p][0] - UR5E_HULL_VERTS[n][0], UR5E_HULL_VERTS[p][1] - UR5E_HULL_VERTS[n][1], UR5E_HULL_VERTS[p][2] - UR5E_HULL_VERTS[n][2]};
-          a = e[au]; b = e[av]; c = s * e[axis];
+          a = su * e[au]; b = sv * e[av]; c = s * e[axis];
         };
         auto meets = [&](int p, int from) -> bool {
           double a, b, c;
