@@ -280,7 +280,11 @@ struct HullMap {
 // of the face's [-1, 1] square against ~1e-7), so a direction that lands in a neighbouring cell -- or, on an exact tie of two
 // components, on the neighbouring FACE -- by rounding still finds its support vertex listed there.
 struct CubeFace { int axis, au, av; double s, su, sv; };  // direction of in-face point (u, v): d[axis] = s, d[au] = su u, d[av] = sv v
-__device__ __forceinline__ CubeFace cube_face(int face) {
+#if defined(URGYM_HOST_HARNESS)
+inline CubeFace cube_face(int face) {
+#else
+__host__ __device__ inline CubeFace cube_face(int face) {
+#endif
   switch (face) {
     case 0: return CubeFace{0, 2, 1, 1.0, -1.0, -1.0};
     case 1: return CubeFace{0, 2, 1, -1.0, 1.0, -1.0};
