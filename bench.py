@@ -287,7 +287,10 @@ def main():
     if gathered is not None:
         check["step"] = args.warmup + args.steps // 2
     torch.cuda.synchronize(dev)
-    env.enable_timing(not args.no_kernel_timing, every=8)  # HIP events around every 8th step launch (an event pair costs the stream ~6 us)
+    # HIP events around every k-th step launch (an event pair costs the stream ~6 us, i.e. ~3 % of a 0.2 ms step if every launch carried
+    # one): every 8th launch in the default 200-step run (25 launches timed), every 2nd in a short one (the driver's 20-step run: 10)
+    every = 8 if args.steps >= 128 else (4 if args.steps >= 64 else 2)
+    env.enable_timing(not args.no_kernel_timing, every=every)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
