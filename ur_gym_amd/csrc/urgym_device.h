@@ -519,121 +519,121 @@ __device__ __forceinline__ void gjk_iterate(GjkRun& r, const HullMap& g, const S
     if (in || f0 <= f1) { URGYM_LANE_MARK(18); fin = 1; }
   }
   if (fin == 0) {
-  stw(T, r.n, w);
-  int n = r.n + 1;
-  URGYM_TRIP_MARK(2);
-  // ---- closest point of the simplex to the origin + vertex reduction
-  // (the vertices the closest point rests on are kept as ONE per-lane bit mask, bit i = vertex i: four booleans that are live across
-  //  the face loop would be four lane masks in scalar registers, merged with three scalar instructions each per pass -- and the loop
-  //  is short of scalar registers)
-  D3 nv = d3(0, 0, 0);
-  bool valid = true;
-  int used = 15;
-  bool reduce = true;
-  if (n == 1) {
-    nv = w;
-    reduce = false;
-  } else if (n == 2) {
-    URGYM_LANE_MARK(3);
-    D3 s0 = W0;
-    D3 e = w - s0;
-    double t = -dot(e, s0);
-    used = 3;
-    if (t > 0.0) {
-      double ee = dot(e, e);
-      if (t < ee) t /= ee;
-      else { t = 1.0; used = 2; }
+    stw(T, r.n, w);
+    int n = r.n + 1;
+    URGYM_TRIP_MARK(2);
+    // ---- closest point of the simplex to the origin + vertex reduction
+    // (the vertices the closest point rests on are kept as ONE per-lane bit mask, bit i = vertex i: four booleans that are live across
+    //  the face loop would be four lane masks in scalar registers, merged with three scalar instructions each per pass -- and the loop
+    //  is short of scalar registers)
+    D3 nv = d3(0, 0, 0);
+    bool valid = true;
+    int used = 15;
+    bool reduce = true;
+    if (n == 1) {
+      nv = w;
+      reduce = false;
+    } else if (n == 2) {
+      URGYM_LANE_MARK(3);
+      D3 s0 = W0;
+      D3 e = w - s0;
+      double t = -dot(e, s0);
+      used = 3;
+      if (t > 0.0) {
+        double ee = dot(e, e);
+        if (t < ee) t /= ee;
+        else { t = 1.0; used = 2; }
+      } else {
+        t = 0.0;
+        used = 1;
+      }
+      nv = s0 + e * t;
     } else {
-      t = 0.0;
-      used = 1;
-    }
-    nv = s0 + e * t;
-  } else {
-    // n == 3: the triangle itself.  n == 4: the faces in Bullet's order ABC|D, ACD|B, ADB|C, BDC|A, each only when the
-    // origin lies on its outer side.  Two passes: (1) the four plane tests, which every lane with a tetrahedron needs,
-    // leave a bit mask of the faces to evaluate; (2) each lane then works through ITS faces, lowest first (Bullet's order:
-    // ties go to the earlier face).  The lanes of a wave rarely have more than two such faces, so pass 2 runs the (one)
-    // triangle routine about twice per wave-wide iteration instead of four times; a lane with a triangle has one "face".
-    const bool tetra = (n == 4);
-    auto face_vertices = [](int f, int& ia, int& ib, int& ic, int& io) {
-      ia = (f == 3) ? 1 : 0;
-      ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3);
-      ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
-      io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
-    };
-    int todo = 1;  // triangle: just face 0 = (w0, w1, w2)
-    bool degen = false;
-    if (tetra) {
-      // the four plane tests as straight-line code on the vertices read above: four independent chains the scheduler can
-      // interleave, instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
-      todo = 0;
-      URGYM_LANE_MARK(4);
-      auto plane = [&](D3 a, D3 b, D3 c, D3 o, int bit) {
-        const D3 nrm = cross(b - a, c - a);
-        const double signp = -dot(a, nrm), signd = dot(o - a, nrm);
-        if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
-        else if (signp * signd < 0.0) todo |= bit;
+      // n == 3: the triangle itself.  n == 4: the faces in Bullet's order ABC|D, ACD|B, ADB|C, BDC|A, each only when the
+      // origin lies on its outer side.  Two passes: (1) the four plane tests, which every lane with a tetrahedron needs,
+      // leave a bit mask of the faces to evaluate; (2) each lane then works through ITS faces, lowest first (Bullet's order:
+      // ties go to the earlier face).  The lanes of a wave rarely have more than two such faces, so pass 2 runs the (one)
+      // triangle routine about twice per wave-wide iteration instead of four times; a lane with a triangle has one "face".
+      const bool tetra = (n == 4);
+      auto face_vertices = [](int f, int& ia, int& ib, int& ic, int& io) {
+        ia = (f == 3) ? 1 : 0;
+        ib = (f == 0) ? 1 : ((f == 1) ? 2 : 3);
+        ic = (f == 0) ? 2 : ((f == 1) ? 3 : ((f == 2) ? 1 : 2));
+        io = (f == 0) ? 3 : ((f == 1) ? 1 : ((f == 2) ? 2 : 0));
       };
-      plane(W0, W1, W2, w, 1);   // ABC | D
-      plane(W0, W2, w, W1, 2);   // ACD | B
-      plane(W0, w, W1, W2, 4);   // ADB | C
-      plane(W1, w, W2, W0, 8);   // BDC | A
-    }
-    URGYM_TRIP_MARK(6);
-    double best = 1.0e300;
-    used = -1;  // no face evaluated yet
+      int todo = 1;  // triangle: just face 0 = (w0, w1, w2)
+      bool degen = false;
+      if (tetra) {
+        // the four plane tests as straight-line code on the vertices read above: four independent chains the scheduler can
+        // interleave, instead of four dependent rounds that each start with an LDS round trip (same expressions, same bits)
+        todo = 0;
+        URGYM_LANE_MARK(4);
+        auto plane = [&](D3 a, D3 b, D3 c, D3 o, int bit) {
+          const D3 nrm = cross(b - a, c - a);
+          const double signp = -dot(a, nrm), signd = dot(o - a, nrm);
+          if (signd * signd < (1.0e-8 * 1.0e-8)) degen = true;
+          else if (signp * signd < 0.0) todo |= bit;
+        };
+        plane(W0, W1, W2, w, 1);   // ABC | D
+        plane(W0, W2, w, W1, 2);   // ACD | B
+        plane(W0, w, W1, W2, 4);   // ADB | C
+        plane(W1, w, W2, W0, 8);   // BDC | A
+      }
+      URGYM_TRIP_MARK(6);
+      double best = 1.0e300;
+      used = -1;  // no face evaluated yet
 #pragma unroll 1
-    while (todo) {
-      const int f = __builtin_ctz((unsigned)todo);
-      todo &= todo - 1;
-      int ia, ib, ic, io;
-      face_vertices(f, ia, ib, ic, io);
-      const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
-      int m3;
-      URGYM_LANE_MARK(5);
-      const D3 pt = tri_closest(a, b, c, m3 URGYM_PROF_PASS(r.clk));
-      const double l = len2(pt);
-      if (used < 0 || l < best) {
-        best = l;
-        nv = pt;
-        used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+      while (todo) {
+        const int f = __builtin_ctz((unsigned)todo);
+        todo &= todo - 1;
+        int ia, ib, ic, io;
+        face_vertices(f, ia, ib, ic, io);
+        const D3 a = ldw(T, ia), b = ldw(T, ib), c = ldw(T, ic);
+        int m3;
+        URGYM_LANE_MARK(5);
+        const D3 pt = tri_closest(a, b, c, m3 URGYM_PROF_PASS(r.clk));
+        const double l = len2(pt);
+        if (used < 0 || l < best) {
+          best = l;
+          nv = pt;
+          used = ((m3 & 1) ? (1 << ia) : 0) | ((m3 & 2) ? (1 << ib) : 0) | ((m3 & 4) ? (1 << ic) : 0);
+        }
+      }
+      if (degen) {
+        valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
+        reduce = false;
+      } else if (used < 0) {
+        nv = d3(0, 0, 0);  // origin inside the tetrahedron
+        reduce = false;
       }
     }
-    if (degen) {
-      valid = false;  // sliver tetrahedron: Bullet's closest() fails, the previous v stands
-      reduce = false;
-    } else if (used < 0) {
-      nv = d3(0, 0, 0);  // origin inside the tetrahedron
-      reduce = false;
+    URGYM_TRIP_MARK(7);
+    if (reduce) {
+      URGYM_LANE_MARK(13);
+      // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
+      if (n >= 4 && !(used & 8)) { n--; }
+      if (n >= 3 && !(used & 4)) { n--; stw(T, 2, ldw(T, n)); }
+      if (n >= 2 && !(used & 2)) { n--; stw(T, 1, ldw(T, n)); }
+      if (n >= 1 && !(used & 1)) { n--; stw(T, 0, ldw(T, n)); }
     }
-  }
-  URGYM_TRIP_MARK(7);
-  if (reduce) {
-    URGYM_LANE_MARK(13);
-    // btVoronoiSimplexSolver::reduceVertices: remove unused vertices from the back, removeVertex(i): w[i] = w[--n]
-    if (n >= 4 && !(used & 8)) { n--; }
-    if (n >= 3 && !(used & 4)) { n--; stw(T, 2, ldw(T, n)); }
-    if (n >= 2 && !(used & 2)) { n--; stw(T, 1, ldw(T, n)); }
-    if (n >= 1 && !(used & 1)) { n--; stw(T, 0, ldw(T, n)); }
-  }
-  r.n = n;
-  if (!valid) fin = 1;  // sliver tetrahedron
-  else {
-    const double nsq = len2(nv);
-    if (nsq < REL_ERROR2) { r.v = nv; fin = 1; }
-    else if (nsq <= verdict_d * verdict_d) { r.v = nv; r.info |= GJK_CLOSE; fin = 1; }
+    r.n = n;
+    if (!valid) fin = 1;  // sliver tetrahedron
     else {
-      const double prev = r.sq;
-      r.sq = nsq;
-      if (prev - nsq <= EPS * prev) fin = 1;  // no progress: the previous v stands
+      const double nsq = len2(nv);
+      if (nsq < REL_ERROR2) { r.v = nv; fin = 1; }
+      else if (nsq <= verdict_d * verdict_d) { r.v = nv; r.info |= GJK_CLOSE; fin = 1; }
       else {
-        r.v = nv;
-        if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; fin = 3; }
-        else if (n == 4) fin = 3;  // the origin is inside the tetrahedron
+        const double prev = r.sq;
+        r.sq = nsq;
+        if (prev - nsq <= EPS * prev) fin = 1;  // no progress: the previous v stands
+        else {
+          r.v = nv;
+          if (r.iter++ > 1000) { r.info |= GJK_ITERCAP; fin = 3; }
+          else if (n == 4) fin = 3;  // the origin is inside the tetrahedron
+        }
       }
     }
-  }
-  }  // fin == 0 before the simplex step
+  }  // (fin == 0: the simplex step)
   if (fin) gjk_finish(r, !(fin & 2), (fin & 4) != 0);
 }
 
