@@ -16,6 +16,7 @@ ap.add_argument("--reset-kernel", action="store_true", help="library built with 
 ap.add_argument("--lib", default="liburgym_stamps.so")
 ap.add_argument("--envs-per-block", type=int, default=64, help="forces URGYM_STEP_ENVS so that the stamp layout is known")
 ap.add_argument("--tiers", default="", help="E1,B,E2: two-tier geometry (URGYM_STEP_TIERS) instead of --envs-per-block")
+ap.add_argument("--no-collision", action="store_true", help="check_collision=0 (BASELINE configs[1]: FK + reward only)")
 args = ap.parse_args()
 os.environ["URGYM_STEP_ENVS"] = str(args.envs_per_block)
 if args.tiers:
@@ -23,7 +24,7 @@ if args.tiers:
 _native.LIB_PATH = os.path.join(os.path.dirname(_native.LIB_PATH), "build", args.lib)
 from ur_gym_amd import make_vec
 
-env = make_vec(args.env, num_envs=args.num_envs, seed=5)
+env = make_vec(args.env, num_envs=args.num_envs, seed=5, check_collision=not args.no_collision)
 env.reset(seed=5)
 gen = torch.Generator(device="cuda").manual_seed(5)
 for _ in range(args.steps):
