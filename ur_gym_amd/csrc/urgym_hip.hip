@@ -719,7 +719,9 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
       }
     }
     const bool live = (n >= 0 && finite);
-    const bool use_cache = (MODE == MODE_STEP) && P.sc_scratch != nullptr;
+    // (the set-up cache serves the draws of closest-distance queries: a launch that runs none -- UR5OriReach-v1 with the collision checks
+    //  off -- does not fill it; its six sin / cos evaluations were a third of that launch's span)
+    const bool use_cache = (MODE == MODE_STEP) && P.sc_scratch != nullptr && (HAS_OBST || cfg.check_collision);
     if (use_cache && live) {  // the set-up cache of this env (KParams::sc_scratch)
 #pragma unroll 1
       for (int k = 0; k < 6; k++) {
