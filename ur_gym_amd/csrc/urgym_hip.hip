@@ -814,7 +814,9 @@ __device__ __forceinline__ void env_body(const KParams& P, const float* __restri
   //   pair bits: the culling survivors of P1, boolean "closer than the margin?" queries, claimed bit by bit once the
   //             tickets are gone.
   //   A lane advances its query by one GJK iteration per loop trip; a finished lane draws the next item.
-  {
+  // (A launch that can have no query at all -- no obstacle, collision checks off: BASELINE configs[1] "FK + reward only" -- skips the
+  //  pool, its polling trip and its barrier: P4 runs on the very lanes that ran P1.)
+  if (!(MODE == MODE_STEP && !HAS_OBST && !cfg.check_collision)) {
     // The operands of a lane's query are carried as (kind, la, lb) only; the shape descriptors are re-derived from them at
     // each use (a handful of selects) instead of living in 16 VGPRs across the loop, which is what used to push the sincos
     // constants of the set-up into scratch.
