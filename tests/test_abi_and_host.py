@@ -172,6 +172,6 @@ def test_bench_reads_the_committed_counters_by_configuration():
         assert name == kernel, (env_id, name)
         assert traffic["corrected"] > traffic["uncorrected"] > 0
         assert 0.0 < valu["valu_frac"] < 1.0 and abs(valu["valu_frac"] - valu["busy_fraction_of_simd_cycles"] * valu["lane_utilisation"]) < 1e-12
-        assert valu["vgprs_elf"] in (163, 168)
+        assert 100 <= valu["vgprs_elf"] <= 168   # three resident workgroups per CU: the 168-VGPR budget
     assert bench.profiled_counters("no such configuration") == (None, None, None)
     assert bench.INFORMATIONAL_BITS == 8 | 32
